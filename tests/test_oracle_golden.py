@@ -1,0 +1,76 @@
+"""The CPU oracle against every golden vector the survey recorded from the
+reference's own fix_ca_region (60 small cases; §8(d): the
+full-size configs, marked slow) and against its own structural properties."""
+import numpy as np
+import pytest
+
+import pyoracle
+from fixca import synth
+from helpers import md5, real_crops, small_input, survey_vectors
+
+VEC = survey_vectors()
+
+
+def test_noise_generator_known_answer():
+    assert list(synth.noise_bytes(1, 8)) == [193, 92, 2, 137, 236, 45, 10, 145]
+
+
+@pytest.mark.parametrize("name", sorted(VEC["inputs"]))
+def test_small_inputs_md5(name):
+    assert md5(small_input(VEC["inputs"][name])) == VEC["inputs"][name]["md5"]
+
+
+@pytest.mark.parametrize("case", VEC["small"], ids=lambda c: "%s-%s-i%d" % (c["input"].replace(" ", ""), c["pset"], c["interpolation"]))
+def test_appendix_c(case):
+    img = small_input(VEC["inputs"][case["input"]], case["width"], case["height"])
+    p = pyoracle.make_params(interpolation=case["interpolation"], **VEC["psets"][case["pset"]])
+    assert md5(pyoracle.region(img, p)) == case["md5"]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", [c for c in VEC["full"] if c["width"] <= 6000], ids=lambda c: c["name"])
+def test_full_size_configs(case):
+    img = synth.noise_image(case["seed"], case["width"], case["height"], case["channels"])
+    assert md5(img) == case["input_md5"]
+    p = pyoracle.make_params(interpolation=case["interpolation"], **case["params"])
+    out = pyoracle.region(img, p, threads=4)      # row bands are independent: same bytes as 1 thread
+    assert md5(out) == case["md5"]
+
+
+@pytest.mark.parametrize("crop", real_crops(), ids=lambda c: c["name"])
+def test_real_crops(crop):
+    assert md5(crop["image"]) == crop["input_md5"]
+    for interp in (0, 1, 2):
+        p = pyoracle.make_params(interpolation=interp, **crop["params"])
+        assert md5(pyoracle.region(crop["image"], p)) == crop["oracle_md5"][str(interp)]
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_identity_when_no_shift(interp):
+    """amounts 0 and shifts 0: scale is exactly 1 and every mode returns the input."""
+    img = synth.noise_image(7, 64, 48, 4)
+    out = pyoracle.region(img, pyoracle.make_params(lens_x=32, lens_y=24, interpolation=interp))
+    assert np.array_equal(out, img)
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_green_alpha_untouched_and_row_range(interp):
+    img = synth.noise_image(9, 70, 50, 4)
+    p = pyoracle.make_params(blue=3.0, red=-2.0, lens_x=10, lens_y=40, interpolation=interp, x_blue=1.5, y_red=-2.25)
+    full = pyoracle.region(img, p)
+    assert np.array_equal(full[..., 1], img[..., 1]) and np.array_equal(full[..., 3], img[..., 3])
+    part = pyoracle.region(img, p, y1=11, y2=37, dst=np.full_like(img, 0xAB))
+    assert np.array_equal(part[11:37], full[11:37])
+    assert np.all(part[:11] == 0xAB) and np.all(part[37:] == 0xAB)      # rows outside [y1,y2) untouched
+
+
+def test_mt_equals_scalar():
+    img = synth.noise_image(11, 129, 97, 3)
+    p = pyoracle.make_params(blue=-3.3, red=4.7, lens_x=-1, lens_y=-1, interpolation=2, x_blue=2.5, y_red=-3)
+    assert np.array_equal(pyoracle.region(img, p), pyoracle.region(img, p, threads=3))
+
+
+def test_refuses_undefined_domain():
+    img = synth.noise_image(3, 16, 16, 4)
+    with pytest.raises(ValueError):        # max_dim + amount <= 0: the reference divides by <= 0
+        pyoracle.region(img, pyoracle.make_params(blue=-30.0, lens_x=8, lens_y=8))
