@@ -1,0 +1,233 @@
+/*
+ * fixca_abi.hip — the extern "C" entry points declared in include/fixca_hip.h.
+ * Thin: validate, plan, launch.  Every failure is reported (code + text); there
+ * is no CPU fallback.
+ */
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/fixca_hip.h"
+#include "fixca_geom.h"
+#include "fixca_internal.h"
+
+extern "C" hipError_t fixca_launch(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_copy(const void *, void *, size_t, hipStream_t);
+
+static thread_local char g_err[512] = "";
+
+int fixca_fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+extern "C" const char *fixca_last_error(void) { return g_err; }
+extern "C" int fixca_abi_version(void) { return 1; }
+
+#define HIP_TRY(call)                                                                       \
+	do {                                                                                    \
+		hipError_t e_ = (call);                                                             \
+		if (e_ != hipSuccess)                                                               \
+			return fixca_fail(FIXCA_E_HIP, "%s: %s", #call, hipGetErrorString(e_));         \
+	} while (0)
+
+/* ---- device plumbing ---------------------------------------------------- */
+
+extern "C" int fixca_device_count(void)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e == hipErrorNoDevice) return 0;
+	if (e != hipSuccess) return fixca_fail(FIXCA_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+	return n;
+}
+
+extern "C" int fixca_set_device(int ordinal)
+{
+	HIP_TRY(hipSetDevice(ordinal));
+	return FIXCA_OK;
+}
+
+extern "C" void *fixca_dev_alloc(size_t nbytes)
+{
+	void *p = NULL;
+	hipError_t e = hipMalloc(&p, nbytes ? nbytes : 1);
+	if (e != hipSuccess) {
+		fixca_fail(FIXCA_E_HIP, "hipMalloc(%zu): %s", nbytes, hipGetErrorString(e));
+		return NULL;
+	}
+	return p;
+}
+
+extern "C" int fixca_dev_free(void *p)
+{
+	HIP_TRY(hipFree(p));
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_copy_h2d(void *d, const void *h, size_t n, void *stream)
+{
+	HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)stream));
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_copy_d2h(void *h, const void *d, size_t n, void *stream)
+{
+	HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_stream_sync(void *stream)
+{
+	HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+	return FIXCA_OK;
+}
+
+static int require_device(void)
+{
+	int n = fixca_device_count();
+	if (n < 0) return n;
+	if (n == 0) return fixca_fail(FIXCA_E_NODEVICE, "no HIP device visible: the Fix-CA GPU path cannot run");
+	return FIXCA_OK;
+}
+
+/* ---- the hot path ------------------------------------------------------- */
+
+extern "C" int fixca_region_device(const void *d_src, void *d_dst, int W, int H, int bytes, int bpc,
+                                   const FixCaParams *params, int x1, int x2, int y1, int y2,
+                                   int show_progress, unsigned flags, void *stream)
+{
+	if (!d_src || !d_dst) return fixca_fail(FIXCA_E_INVALID, "null image pointer");
+	if (d_src == d_dst) return fixca_fail(FIXCA_E_INVALID, "src and dst must not alias");
+	FixcaGeom g;
+	FixcaPlan pl;
+	int rc = fixca_make_geom(W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, &g);
+	if (rc) return rc;
+	rc = fixca_make_plan(&g, flags, &pl);
+	if (rc) return rc;
+	HIP_TRY(fixca_launch(d_src, d_dst, &g, &pl, (hipStream_t)stream));
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_batch_device(const void *const *d_src, void *const *d_dst, int n_images,
+                                  int W, int H, int bytes, int bpc, const FixCaParams *params,
+                                  unsigned flags, void *stream)
+{
+	if (!d_src || !d_dst || n_images < 0) return fixca_fail(FIXCA_E_INVALID, "bad batch arguments");
+	FixcaGeom g;
+	FixcaPlan pl;
+	int rc = fixca_make_geom(W, H, bytes, bpc, params, 0, W, 0, H, 1, &g);
+	if (rc) return rc;
+	rc = fixca_make_plan(&g, flags, &pl);
+	if (rc) return rc;
+	for (int i = 0; i < n_images; ++i) {
+		if (!d_src[i] || !d_dst[i] || d_src[i] == d_dst[i])
+			return fixca_fail(FIXCA_E_INVALID, "image %d: null or aliased pointers", i);
+		HIP_TRY(fixca_launch(d_src[i], d_dst[i], &g, &pl, (hipStream_t)stream));
+	}
+	return FIXCA_OK;
+}
+
+/* fixca_region_host keeps its two device images between calls (grow only) */
+static void  *g_cache[2] = { NULL, NULL };
+static size_t g_cache_bytes = 0;
+
+extern "C" void fixca_release_cache(void)
+{
+	for (int i = 0; i < 2; ++i) {
+		if (g_cache[i]) (void)hipFree(g_cache[i]);
+		g_cache[i] = NULL;
+	}
+	g_cache_bytes = 0;
+}
+
+extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, int W, int H, int bytes,
+                                 int bpc, const FixCaParams *params, int x1, int x2, int y1, int y2,
+                                 int show_progress)
+{
+	if (!src || !dst) return fixca_fail(FIXCA_E_INVALID, "null image pointer");
+	FixcaGeom g;
+	int rc = fixca_make_geom(W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, &g);
+	if (rc) return rc;                       /* argument errors are reported without touching the GPU */
+	rc = require_device();
+	if (rc) return rc;
+
+	const size_t pitch = (size_t)W * bytes, total = pitch * H;
+	if (total > g_cache_bytes) {
+		fixca_release_cache();
+		HIP_TRY(hipMalloc(&g_cache[0], total));
+		HIP_TRY(hipMalloc(&g_cache[1], total));
+		g_cache_bytes = total;
+	}
+	const char *ex = getenv("FIXCA_EXACT");
+	const unsigned flags = (ex && *ex && strcmp(ex, "0") != 0) ? FIXCA_KERNEL_EXACT : FIXCA_KERNEL_AUTO;
+
+	HIP_TRY(hipMemcpy(g_cache[0], src, total, hipMemcpyHostToDevice));
+	rc = fixca_region_device(g_cache[0], g_cache[1], W, H, bytes, bpc, params, x1, x2, y1, y2,
+	                         show_progress, flags, NULL);
+	if (rc) return rc;
+	if (y2 > y1)
+		HIP_TRY(hipMemcpy(dst + (size_t)y1 * pitch, (const char *)g_cache[1] + (size_t)y1 * pitch,
+		                  (size_t)(y2 - y1) * pitch, hipMemcpyDeviceToHost));
+	HIP_TRY(hipDeviceSynchronize());
+	return FIXCA_OK;
+}
+
+/* ---- timing on the launch stream ---------------------------------------- */
+
+extern "C" int fixca_time_launches(const void *const *d_src, void *const *d_dst, int n_pairs, int launches,
+                                   int W, int H, int bytes, int bpc, const FixCaParams *params,
+                                   unsigned flags, void *stream, double *ms_per_launch)
+{
+	if (!d_src || !d_dst || n_pairs < 1 || launches < 1 || !ms_per_launch)
+		return fixca_fail(FIXCA_E_INVALID, "bad timing arguments");
+	FixcaGeom g;
+	FixcaPlan pl;
+	int rc = fixca_make_geom(W, H, bytes, bpc, params, 0, W, 0, H, 1, &g);
+	if (rc) return rc;
+	rc = fixca_make_plan(&g, flags, &pl);
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, st));
+	for (int i = 0; i < launches; ++i)
+		HIP_TRY(fixca_launch(d_src[i % n_pairs], d_dst[i % n_pairs], &g, &pl, st));
+	HIP_TRY(hipEventRecord(e1, st));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*ms_per_launch = (double)ms / launches;
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_time_copy(const void *const *d_src, void *const *d_dst, int n_pairs, int launches,
+                               size_t nbytes, void *stream, double *ms_per_launch)
+{
+	if (!d_src || !d_dst || n_pairs < 1 || launches < 1 || !ms_per_launch)
+		return fixca_fail(FIXCA_E_INVALID, "bad timing arguments");
+	hipStream_t st = (hipStream_t)stream;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, st));
+	for (int i = 0; i < launches; ++i)
+		HIP_TRY(fixca_launch_copy(d_src[i % n_pairs], d_dst[i % n_pairs], nbytes, st));
+	HIP_TRY(hipEventRecord(e1, st));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*ms_per_launch = (double)ms / launches;
+	return FIXCA_OK;
+}

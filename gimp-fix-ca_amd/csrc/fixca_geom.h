@@ -1,0 +1,40 @@
+/*
+ * fixca_geom.h — geometry of one fix_ca_region call, shared by the host planner
+ * and the gfx950 kernels.  Plain C++ (no HIP types) so the planner also builds
+ * and unit-tests on a machine without a GPU.
+ */
+#ifndef FIXCA_GEOM_H
+#define FIXCA_GEOM_H
+
+#include <stdint.h>
+
+/* channel index: 0 = red (byte 0 of a pixel), 1 = blue (byte 2), bpc == 1 */
+struct FixcaGeom {
+	int    W, H;        /* image size in pixels (orig_width, orig_height)   */
+	int    bpp;         /* bytes per pixel: 3 (RGB8) or 4 (RGBA8)           */
+	int    xc, yc;      /* lens centre, C-truncated (fix-ca.c:1033-1034)    */
+	int    y1, y2;      /* rows to produce                                   */
+	int    interp;      /* 0 none, 1 linear, 2 cubic                         */
+	double s[2];        /* scale about the centre (fix-ca.c:1044-1045)      */
+	double xs[2];       /* directional x shift                               */
+	double ys[2];       /* directional y shift                               */
+};
+
+/* launch shape chosen by the planner */
+struct FixcaPlan {
+	int kernel;         /* 1 exact, 2 fast-none, 3 fast-interp               */
+	int oc;             /* output columns per wave (multiple of 4)           */
+	int th;             /* output rows per wave (<= 64)                      */
+	int nstrips;        /* ceil(W / oc)                                      */
+	int nchunks;        /* ceil((y2 - y1) / th)                              */
+	int nwaves;         /* nstrips * nchunks                                 */
+	int nblocks;        /* 256-thread blocks, padded to a multiple of 8      */
+};
+
+#define FIXCA_K_EXACT   1
+#define FIXCA_K_NONE    2
+#define FIXCA_K_INTERP  3
+
+#define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
+
+#endif

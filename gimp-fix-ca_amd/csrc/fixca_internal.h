@@ -1,0 +1,17 @@
+/* fixca_internal.h — shared between the planner and the C-ABI translation unit. */
+#ifndef FIXCA_INTERNAL_H
+#define FIXCA_INTERNAL_H
+
+#include <stddef.h>
+#include "../../include/fixca_types.h"
+#include "fixca_geom.h"
+
+/* records the message for fixca_last_error() and returns code */
+int fixca_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+int  fixca_make_geom(int W, int H, int bytes, int bpc, const FixCaParams *p,
+                     int x1, int x2, int y1, int y2, int show_progress, FixcaGeom *g);
+int  fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl);
+void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n);
+
+#endif

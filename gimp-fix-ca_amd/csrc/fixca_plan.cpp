@@ -1,0 +1,188 @@
+/*
+ * fixca_plan.cpp — host-side argument validation, geometry and launch planning.
+ * No HIP calls here: this file also runs on a machine without a GPU (the
+ * planner is exported through fixca_plan_describe and unit-tested on CPU).
+ *
+ * Compiled with -ffp-contract=off: the coordinate arithmetic below must round
+ * exactly like the kernels' (and the reference's) un-fused double expression.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/fixca_hip.h"
+#include "fixca_geom.h"
+#include "fixca_internal.h"
+
+static double h_coord(int i, int centre, double s, double shift)
+{
+	return (i - centre) * s + centre - shift;            /* fix-ca.c:801, :813 */
+}
+
+static double h_map_dbl(int i, int centre, int size, double s, double shift)
+{
+	double d = h_coord(i, centre, s, shift);
+	if (d <= 0.0) return 0.0;
+	if (d >= size - 1) return size - 1;
+	return d;
+}
+
+static int trunc_to_int(double d)
+{
+	if (!(d > (double)INT_MIN)) return INT_MIN + 1;       /* also NaN */
+	if (d >= (double)INT_MAX) return INT_MAX;
+	return (int)d;
+}
+
+extern "C" int fixca_params_check(const FixCaParams *p)
+{
+	/* run()'s non-interactive range check, fix-ca.c:279-295 */
+	if (!p) return FIXCA_E_INVALID;
+	const double m = FIXCA_INPUT_MAX;
+	const double v[6] = { p->blue, p->red, p->x_blue, p->x_red, p->y_blue, p->y_red };
+	for (int i = 0; i < 6; ++i)
+		if (!(v[i] >= -m && v[i] <= m)) return FIXCA_E_DOMAIN;
+	if (p->interpolation < 0 || p->interpolation > 2) return FIXCA_E_DOMAIN;
+	return FIXCA_OK;
+}
+
+int fixca_make_geom(int W, int H, int bytes, int bpc, const FixCaParams *p,
+                    int x1, int x2, int y1, int y2, int show_progress, FixcaGeom *g)
+{
+	if (!p || !g) return fixca_fail(FIXCA_E_INVALID, "null parameter block");
+	if (W <= 0 || H <= 0) return fixca_fail(FIXCA_E_INVALID, "image size %dx%d", W, H);
+	if (y1 < 0 || y2 > H || y1 > y2)
+		return fixca_fail(FIXCA_E_INVALID, "row range [%d,%d) outside 0..%d", y1, y2, H);
+	if (x1 != 0 || x2 != W)
+		return fixca_fail(FIXCA_E_UNSUPPORTED,
+		                  "column range [%d,%d) != [0,%d): the reference indexes partial columns wrongly "
+		                  "(fix-ca.c:855,1084,1098); only full-width calls are defined", x1, x2, W);
+	if (bpc != 1 || (bytes != 3 && bytes != 4))
+		return fixca_fail(FIXCA_E_UNSUPPORTED, "bpc=%d bytes=%d: only 8-bit RGB/RGBA is implemented", bpc, bytes);
+	if (!show_progress)
+		return fixca_fail(FIXCA_E_UNSUPPORTED, "preview path (show_progress=0: saturate+centerline) is not implemented");
+	if (p->interpolation < 0 || p->interpolation > 2)
+		return fixca_fail(FIXCA_E_DOMAIN, "interpolation %d not in 0..2", p->interpolation);
+
+	g->W = W; g->H = H; g->bpp = bytes;
+	g->xc = trunc_to_int(p->lens_x);                      /* fix-ca.c:1033-1034 */
+	g->yc = trunc_to_int(p->lens_y);
+	g->y1 = y1; g->y2 = y2;
+	g->interp = p->interpolation;
+
+	long long max_dim = (g->xc >= g->yc) ? g->xc : g->yc;  /* fix-ca.c:1036-1043 */
+	if ((long long)W - g->xc > max_dim) max_dim = (long long)W - g->xc;
+	if ((long long)H - g->yc > max_dim) max_dim = (long long)H - g->yc;
+	if (max_dim > INT_MAX) max_dim = INT_MAX;
+	const int md = (int)max_dim;
+	if (!(md + p->red > 0) || !(md + p->blue > 0))
+		return fixca_fail(FIXCA_E_DOMAIN, "max_dim %d + amount <= 0 (red %g, blue %g): the reference divides by <= 0",
+		                  md, p->red, p->blue);
+	g->s[0] = md / (md + p->red);                         /* fix-ca.c:1045 */
+	g->s[1] = md / (md + p->blue);                        /* fix-ca.c:1044 */
+	g->xs[0] = p->x_red;  g->ys[0] = p->y_red;
+	g->xs[1] = p->x_blue; g->ys[1] = p->y_blue;
+	for (int c = 0; c < 2; ++c)
+		if (!isfinite(g->s[c]) || !isfinite(g->xs[c]) || !isfinite(g->ys[c]) || !(g->s[c] > 0))
+			return fixca_fail(FIXCA_E_DOMAIN, "non-finite or non-positive scale/shift");
+	return FIXCA_OK;
+}
+
+static int env_int(const char *name, int dflt, int lo, int hi)
+{
+	const char *e = getenv(name);
+	if (!e || !*e) return dflt;
+	int v = atoi(e);
+	if (v < lo) v = lo;
+	if (v > hi) v = hi;
+	return v;
+}
+
+/* does every strip's source window fit the 256 columns a wave filters? */
+static bool interp_fits(const FixcaGeom *g, int oc, int taps)
+{
+	const int back = (taps == 4) ? 1 : 0;
+	for (int c = 0; c < 2; ++c)
+		for (int X0 = 0; X0 < g->W; X0 += oc) {
+			int xl = X0 + oc - 1;
+			if (xl > g->W - 1) xl = g->W - 1;
+			int S0 = (int)floor(h_map_dbl(X0, g->xc, g->W, g->s[c], g->xs[c])) - back;
+			int last = (int)floor(h_map_dbl(xl, g->xc, g->W, g->s[c], g->xs[c])) - back - S0 + taps - 1;
+			if (last > FIXCA_WAVE_COLS - 1) return false;
+		}
+	return true;
+}
+
+static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
+{
+	int rows = g->y2 - g->y1;
+	pl->nstrips = (g->W + pl->oc - 1) / pl->oc;
+	pl->nchunks = (rows + pl->th - 1) / pl->th;
+	if (pl->nchunks < 1) pl->nchunks = 1;
+	pl->nwaves = pl->nstrips * pl->nchunks;
+	pl->nblocks = ((pl->nwaves + 3) / 4 + 7) & ~7;
+}
+
+int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
+{
+	const unsigned want = flags & FIXCA_KERNEL_MASK;
+	memset(pl, 0, sizeof *pl);
+	pl->kernel = FIXCA_K_EXACT;
+	if (want == FIXCA_KERNEL_EXACT) return FIXCA_OK;
+
+	/* the fast kernels load 4 pixels at a time and index rows/columns with int */
+	const bool size_ok = g->W >= 8 && (long long)g->W * g->H * g->bpp < (1LL << 40);
+	const int th = env_int("FIXCA_TH", 32, 1, 64);
+
+	if (size_ok && g->interp == 0) {
+		pl->kernel = FIXCA_K_NONE;
+		pl->oc = FIXCA_WAVE_COLS;
+		pl->th = th;
+		finish_plan(g, pl);
+		return FIXCA_OK;
+	}
+	if (size_ok && g->interp != 0) {
+		const int taps = (g->interp == 2) ? 4 : 2;
+		int oc_max = env_int("FIXCA_OC", 252, 16, 252) & ~3;
+		for (int oc = oc_max; oc >= 64; oc -= 4) {
+			if (!interp_fits(g, oc, taps)) continue;
+			pl->kernel = FIXCA_K_INTERP;
+			pl->oc = oc;
+			pl->th = th;
+			finish_plan(g, pl);
+			return FIXCA_OK;
+		}
+	}
+	if (want == FIXCA_KERNEL_FAST)
+		return fixca_fail(FIXCA_E_UNSUPPORTED, "no fast plan for %dx%d scale %.6g/%.6g (width < 8 or scale too far from 1)",
+		                  g->W, g->H, g->s[0], g->s[1]);
+	return FIXCA_OK;
+}
+
+void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n)
+{
+	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp" };
+	static const char *in[] = { "none", "linear", "cubic" };
+	if (!buf || !n) return;
+	if (pl->kernel == FIXCA_K_EXACT)
+		snprintf(buf, n, "%s %s bpp=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, (g->W + 255) / 256, g->y2 - g->y1);
+	else
+		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d strips=%d chunks=%d waves=%d blocks=%d", kn[pl->kernel],
+		         in[g->interp], g->bpp, pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->nblocks);
+}
+
+extern "C" int fixca_plan_describe(int W, int H, int bytes, int bpc, const FixCaParams *p,
+                                   int x1, int x2, int y1, int y2, int show_progress,
+                                   unsigned flags, char *buf, size_t buflen)
+{
+	FixcaGeom g;
+	FixcaPlan pl;
+	int rc = fixca_make_geom(W, H, bytes, bpc, p, x1, x2, y1, y2, show_progress, &g);
+	if (rc) return rc;
+	rc = fixca_make_plan(&g, flags, &pl);
+	if (rc) return rc;
+	fixca_plan_text(&g, &pl, buf, buflen);
+	return pl.kernel;
+}

@@ -1,0 +1,134 @@
+/*
+ * fixca_hip.h — C-ABI of libfixca_hip.so, the MI355X (gfx950) implementation of
+ * the Fix-CA plug-in's pixel loop.
+ *
+ * The boundary is the reference's own function
+ *
+ *     static void fix_ca_region (guchar *srcPTR, guchar *dstPTR,
+ *                                gint orig_width, gint orig_height,
+ *                                gint bytes, gint bpc, FixCaParams *params,
+ *                                gint x1, gint x2, gint y1, gint y2,
+ *                                gboolean show_progress);     fix-ca.c:105-109, :998-1001
+ *
+ * called by fix_ca() (fix-ca.c:373, whole drawable) and preview_update()
+ * (fix-ca.c:656, visible rows).  Every entry below takes plain pointers and
+ * sizes; no GIMP, glib, torch or HIP types appear in a signature (a stream is
+ * passed as void*).  All entries return FIXCA_OK (0) or a negative FIXCA_E_*
+ * code and never abort the process; fixca_last_error() gives the text.  There is
+ * no CPU fallback inside the library: if the GPU path cannot run, the call fails.
+ */
+#ifndef FIXCA_HIP_H
+#define FIXCA_HIP_H
+
+#include <stddef.h>
+#include "fixca_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIXCA_API __attribute__((visibility("default")))
+
+/* ---- status codes ------------------------------------------------------- */
+#define FIXCA_OK              0
+#define FIXCA_E_INVALID      (-1)  /* null pointer, non-positive size, bad row range   */
+#define FIXCA_E_UNSUPPORTED  (-2)  /* x1 != 0 or x2 != orig_width (reference indexes
+                                      wrongly there); bpc/bytes pair not
+                                      implemented; preview path (show_progress == 0)  */
+#define FIXCA_E_DOMAIN       (-3)  /* max_dim + amount <= 0, |amount| > 30, interp ∉ 0..2 */
+#define FIXCA_E_HIP          (-4)  /* a HIP runtime call failed                        */
+#define FIXCA_E_NODEVICE     (-5)  /* no gfx950 device visible                         */
+
+/* ---- kernel selection flags (device entries) ---------------------------- */
+#define FIXCA_KERNEL_AUTO   0u   /* fast row-scan kernel when its plan fits, else exact */
+#define FIXCA_KERNEL_EXACT  1u   /* fp64 kernel, operation for operation the reference's
+                                    arithmetic: bit-exact in all three modes            */
+#define FIXCA_KERNEL_FAST   2u   /* fast kernel or FIXCA_E_UNSUPPORTED (tests, bench)   */
+#define FIXCA_KERNEL_MASK   3u
+
+/*
+ * Replaces the body of fix_ca_region (fix-ca.c:998-1348) for host buffers.
+ * Same argument order and meaning.  Copies src to the device, runs the kernel on
+ * rows [y1,y2), copies exactly those rows back into dst; rows of dst outside
+ * [y1,y2) are not written (set_data, fix-ca.c:864-871, writes only row y).
+ * Buffers are borrowed for the duration of the call.  Synchronous.
+ * Kernel choice: FIXCA_KERNEL_AUTO, or FIXCA_KERNEL_EXACT when the environment
+ * variable FIXCA_EXACT is set to a non-zero value.
+ */
+FIXCA_API int fixca_region_host(const unsigned char *src, unsigned char *dst,
+                                int orig_width, int orig_height, int bytes, int bpc,
+                                const FixCaParams *params,
+                                int x1, int x2, int y1, int y2, int show_progress);
+
+/*
+ * The same call on buffers already resident in device memory (hipMalloc'd or a
+ * torch tensor's data_ptr).  Asynchronous on `stream` (a hipStream_t, NULL = the
+ * default stream); the caller synchronises.  src and dst must not overlap.
+ */
+FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
+                                  int orig_width, int orig_height, int bytes, int bpc,
+                                  const FixCaParams *params,
+                                  int x1, int x2, int y1, int y2, int show_progress,
+                                  unsigned flags, void *stream);
+
+/*
+ * A batch of independent images of one geometry and one parameter block (the
+ * "512 images" configuration): image i is d_src[i] -> d_dst[i], all rows.  The
+ * pointer arrays are host arrays of device pointers.  One launch per image, back
+ * to back on `stream`.
+ */
+FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, int n_images,
+                                 int orig_width, int orig_height, int bytes, int bpc,
+                                 const FixCaParams *params, unsigned flags, void *stream);
+
+/*
+ * Which kernel the planner picks for a call, without launching anything (usable
+ * with no GPU).  Writes a short description ("fast-cubic oc=248 th=32 ...") into
+ * buf and returns the kernel id: 1 = exact, 2 = fast-none, 3 = fast-interp;
+ * negative FIXCA_E_* if the call itself would be refused.
+ */
+FIXCA_API int fixca_plan_describe(int orig_width, int orig_height, int bytes, int bpc,
+                                  const FixCaParams *params, int x1, int x2, int y1, int y2,
+                                  int show_progress, unsigned flags, char *buf, size_t buflen);
+
+/*
+ * Validates a parameter block the way run() does for non-interactive calls
+ * (fix-ca.c:279-295): every amount within ±FIXCA_INPUT_MAX, interpolation 0..2.
+ */
+FIXCA_API int fixca_params_check(const FixCaParams *params);
+
+/* ---- device plumbing for C hosts (the plug-in has no torch) ------------- */
+FIXCA_API int   fixca_device_count(void);             /* >= 0, or FIXCA_E_HIP         */
+FIXCA_API int   fixca_set_device(int ordinal);
+FIXCA_API void *fixca_dev_alloc(size_t nbytes);        /* NULL on failure              */
+FIXCA_API int   fixca_dev_free(void *d_ptr);
+FIXCA_API int   fixca_copy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
+FIXCA_API int   fixca_copy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
+FIXCA_API int   fixca_stream_sync(void *stream);
+FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_host's buffers */
+
+/* ---- timing on the launch stream (bench.py's roofline leg) -------------- */
+/*
+ * Runs `launches` back-to-back kernel launches over the n_pairs src/dst pairs in
+ * rotation on `stream`, bracketed by HIP events recorded on that same stream, and
+ * returns the mean milliseconds per launch in *ms_per_launch.
+ */
+FIXCA_API int fixca_time_launches(const void *const *d_src, void *const *d_dst, int n_pairs,
+                                  int launches, int orig_width, int orig_height, int bytes,
+                                  int bpc, const FixCaParams *params, unsigned flags,
+                                  void *stream, double *ms_per_launch);
+
+/*
+ * A plain 16-byte-per-lane device copy of nbytes (the on-box bandwidth ceiling the
+ * kernel is compared with), timed the same way.
+ */
+FIXCA_API int fixca_time_copy(const void *const *d_src, void *const *d_dst, int n_pairs,
+                              int launches, size_t nbytes, void *stream, double *ms_per_launch);
+
+FIXCA_API const char *fixca_last_error(void);          /* thread-local, never NULL     */
+FIXCA_API int         fixca_abi_version(void);         /* 1                            */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIXCA_HIP_H */

@@ -1,0 +1,105 @@
+"""CPU checks of the C-ABI: the library loads, exports every symbol the header
+declares, refuses bad calls with the documented codes, and never computes
+without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fixca
+
+
+def _declared(repo_root):
+    text = open(os.path.join(repo_root, "include", "fixca_hip.h")).read()
+    return sorted(set(re.findall(r"FIXCA_API\s+[\w\s\*]+?\b(fixca_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported(repo_root):
+    names = _declared(repo_root)
+    assert len(names) >= 17
+    raw = ctypes.CDLL(fixca.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "missing export " + n
+    assert sorted(fixca.ABI_SYMBOLS) == names       # the binding covers exactly the header
+
+
+def test_no_internal_symbols_leak():
+    raw = ctypes.CDLL(fixca.LIB_PATH)
+    for n in ("fixca_launch", "fixca_make_plan", "fixca_fail"):
+        assert not hasattr(raw, n)
+
+
+def test_params_layout():
+    assert ctypes.sizeof(fixca.FixCaParams) == 80
+    offs = {n: getattr(fixca.FixCaParams, n).offset for n, _ in fixca.FixCaParams._fields_}
+    assert offs == dict(blue=0, red=8, lens_x=16, lens_y=24, update_preview=32, interpolation=36,
+                        saturation=40, x_blue=48, x_red=56, y_blue=64, y_red=72)
+    d = fixca.default_params()                      # fix-ca.c:85-97
+    assert (d.lens_x, d.lens_y, d.interpolation, d.update_preview) == (-1.0, -1.0, 1, 1)
+    assert fixca.lib.fixca_abi_version() == 1
+
+
+def test_params_check_matches_run_range():
+    ok = fixca.make_params(blue=30, red=-30, interpolation=2, x_blue=-30, y_red=30)
+    assert fixca.params_check(ok)
+    for bad in (dict(blue=30.01), dict(red=-31), dict(interpolation=3), dict(interpolation=-1),
+                dict(x_blue=31), dict(y_red=float("nan"))):
+        assert not fixca.params_check(fixca.make_params(**bad)), bad
+
+
+@pytest.mark.parametrize("kwargs,code", [
+    (dict(x1=1), fixca.E_UNSUPPORTED),              # partial columns: undefined in the reference
+    (dict(x2=10), fixca.E_UNSUPPORTED),
+    (dict(y1=-1), fixca.E_INVALID),
+    (dict(y2=99), fixca.E_INVALID),
+    (dict(y1=9, y2=3), fixca.E_INVALID),
+    (dict(show_progress=False), fixca.E_UNSUPPORTED),
+])
+def test_plan_refusals(kwargs, code):
+    p = fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8)
+    with pytest.raises(fixca.FixCaError) as e:
+        fixca.plan(32, 16, 4, 1, p, **kwargs)
+    assert e.value.code == code and str(e.value)
+
+
+def test_plan_refuses_formats_and_domain():
+    p = fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8)
+    for bytes_, bpc in ((8, 2), (16, -4), (2, 1), (5, 1)):
+        with pytest.raises(fixca.FixCaError) as e:
+            fixca.plan(32, 16, bytes_, bpc, p)
+        assert e.value.code == fixca.E_UNSUPPORTED
+    with pytest.raises(fixca.FixCaError) as e:      # max_dim 16 + (-20) <= 0
+        fixca.plan(32, 16, 4, 1, fixca.make_params(blue=-20, lens_x=16, lens_y=8))
+    assert e.value.code == fixca.E_DOMAIN
+    with pytest.raises(fixca.FixCaError) as e:
+        fixca.plan(32, 16, 4, 1, fixca.make_params(interpolation=7))
+    assert e.value.code == fixca.E_DOMAIN
+
+
+def test_planner_choices():
+    cub = fixca.make_params(blue=2, red=-2, lens_x=658, lens_y=1280, interpolation=2)
+    k, desc = fixca.plan(6000, 4000, 4, 1, cub)
+    assert k == 3 and "fast-interp cubic" in desc and "oc=252" in desc
+    k, desc = fixca.plan(6000, 4000, 4, 1, fixca.make_params(blue=1.5, red=-1.5, lens_x=3000, lens_y=2000))
+    assert k == 2 and "fast-none" in desc
+    assert fixca.plan(6000, 4000, 4, 1, cub, kernel=fixca.KERNEL_EXACT)[0] == 1
+    assert fixca.plan(6, 6, 3, 1, fixca.make_params(lens_x=3, lens_y=3, interpolation=1))[0] == 1   # too narrow
+    with pytest.raises(fixca.FixCaError):
+        fixca.plan(6, 6, 3, 1, fixca.make_params(lens_x=3, lens_y=3, interpolation=1), kernel=fixca.KERNEL_FAST)
+    # strong magnification: the source window of a 252-column strip no longer fits 256 columns
+    k, desc = fixca.plan(2000, 100, 4, 1, fixca.make_params(red=-30, lens_x=200, lens_y=50, interpolation=2))
+    oc = int(re.search(r"oc=(\d+)", desc).group(1))
+    assert k == 3 and oc < 252 and oc % 4 == 0
+    assert fixca.plan(2000, 100, 4, 1, cub, y1=10, y2=10)[0] == 3      # empty row range is legal
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    img = np.zeros((16, 32, 4), np.uint8)
+    with pytest.raises(fixca.FixCaError) as e:
+        fixca.fix_ca_image(img, fixca.make_params(blue=1, lens_x=16, lens_y=8))
+    assert e.value.code in (fixca.E_NODEVICE, fixca.E_HIP)

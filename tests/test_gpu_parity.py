@@ -1,0 +1,277 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the
+C-ABI (libfixca_hip.so via ctypes).  The checker is the CPU oracle and the
+golden md5 vectors recorded from the reference (tests/golden/survey_vectors.json).
+
+Bars: interpolation NONE bit-exact on every kernel; the fp64 kernel bit-exact in
+all three modes; the fast LINEAR/CUBIC kernel within 1 LSB per 8-bit channel
+(BASELINE.json north_star), green/alpha always exact.
+"""
+import numpy as np
+import pytest
+
+import fixca
+import pyoracle
+from fixca import synth
+from helpers import diff_stats, md5, real_crops, small_input, survey_vectors
+
+pytestmark = pytest.mark.gpu
+
+VEC = survey_vectors()
+TOL_LSB = 1          # north_star: within +-1 LSB per 8-bit channel for linear / cubic
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "no GPU: run these with -m gpu on the MI355X box"
+    assert fixca.device_count() >= 1
+    return torch
+
+
+def gpu_run(torch, img, params, kernel, y1=0, y2=None, fill=None):
+    """device entry on torch tensors; returns a numpy image"""
+    h, w, c = img.shape
+    y2 = h if y2 is None else y2
+    src = torch.from_numpy(img).cuda()
+    dst = torch.empty_like(src) if fill is None else torch.full_like(src, fill)
+    fixca.fix_ca_region(src, dst, w, h, c, 1, params, 0, w, y1, y2, True, kernel)
+    torch.cuda.synchronize()
+    return dst.cpu().numpy()
+
+
+def oracle_run(img, params, **kw):
+    return pyoracle.region(img, pyoracle.make_params(**params.as_dict()), **kw)
+
+
+# ---- golden vectors recorded from the reference ---------------------------------
+
+@pytest.mark.parametrize("case", VEC["small"], ids=lambda c: "%s-%s-i%d" % (c["input"].replace(" ", ""), c["pset"], c["interpolation"]))
+def test_exact_kernel_matches_reference_md5(torch_cuda, case):
+    img = small_input(VEC["inputs"][case["input"]], case["width"], case["height"])
+    p = fixca.make_params(interpolation=case["interpolation"], **VEC["psets"][case["pset"]])
+    out = gpu_run(torch_cuda, img, p, fixca.KERNEL_EXACT)
+    assert md5(out) == case["md5"]
+
+
+@pytest.mark.parametrize("case", VEC["small"], ids=lambda c: "%s-%s-i%d" % (c["input"].replace(" ", ""), c["pset"], c["interpolation"]))
+def test_fast_kernel_against_reference_vectors(torch_cuda, case):
+    img = small_input(VEC["inputs"][case["input"]], case["width"], case["height"])
+    p = fixca.make_params(interpolation=case["interpolation"], **VEC["psets"][case["pset"]])
+    out = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST)
+    if case["interpolation"] == 0:
+        assert md5(out) == case["md5"]                      # bit-exact
+        return
+    ref = oracle_run(img, p)
+    assert md5(ref) == case["md5"]                          # the checker itself is pinned
+    mx, n = diff_stats(out, ref)
+    assert mx <= TOL_LSB
+    assert n <= 0.02 * ref.size
+    assert np.array_equal(out[..., 1], img[..., 1])         # green untouched
+    if img.shape[2] == 4:
+        assert np.array_equal(out[..., 3], img[..., 3])     # alpha untouched
+
+
+@pytest.mark.parametrize("crop", real_crops(), ids=lambda c: c["name"])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_real_image_crops(torch_cuda, crop, interp):
+    p = fixca.make_params(interpolation=interp, **crop["params"])
+    exact = gpu_run(torch_cuda, crop["image"], p, fixca.KERNEL_EXACT)
+    assert md5(exact) == crop["oracle_md5"][str(interp)]
+    auto = gpu_run(torch_cuda, crop["image"], p, fixca.KERNEL_AUTO)
+    mx, _ = diff_stats(auto, exact)
+    assert mx <= (0 if interp == 0 else TOL_LSB)
+
+
+# ---- shapes and edges -------------------------------------------------------------
+
+SHAPES = [(8, 1, 4), (8, 5, 3), (9, 9, 3), (11, 7, 4), (64, 40, 4), (253, 33, 3), (255, 65, 4), (256, 64, 4),
+          (300, 70, 3), (505, 37, 4), (1000, 50, 4), (1021, 67, 3)]
+EDGE_PARAMS = [
+    dict(blue=1.5, red=-1.5, lens_x=0.5, lens_y=0.5),
+    dict(blue=-3.3, red=4.7, lens_x=-1, lens_y=-1, x_blue=2.5, x_red=-1.25, y_blue=.75, y_red=-3),
+    dict(blue=-20, red=25, lens_x=0.33, lens_y=0.5, x_blue=-29, x_red=30, y_blue=30, y_red=-30),
+    dict(lens_x=0.5, lens_y=0.5, x_blue=30, x_red=-30, y_blue=-30, y_red=30),
+]
+
+
+def _scaled(kw, w, h):
+    kw = dict(kw)
+    for k, n in (("lens_x", w), ("lens_y", h)):
+        if 0 < kw[k] < 1:
+            kw[k] = int(kw[k] * n)
+    return kw
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%dx%d" % s)
+@pytest.mark.parametrize("pi", range(len(EDGE_PARAMS)))
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_shapes_and_parameter_extremes(torch_cuda, shape, pi, interp):
+    w, h, c = shape
+    kw = _scaled(EDGE_PARAMS[pi], w, h)
+    p = fixca.make_params(interpolation=interp, **kw)
+    try:
+        fixca.plan(w, h, c, 1, p)
+    except fixca.FixCaError as e:
+        assert e.code == fixca.E_DOMAIN                     # tiny image, big negative amount
+        return
+    img = synth.noise_image(1000 + w + h, w, h, c)
+    ref = oracle_run(img, p)
+    exact = gpu_run(torch_cuda, img, p, fixca.KERNEL_EXACT)
+    assert np.array_equal(exact, ref)
+    auto = gpu_run(torch_cuda, img, p, fixca.KERNEL_AUTO)
+    mx, n = diff_stats(auto, ref)
+    assert mx <= (0 if interp == 0 else TOL_LSB)
+    assert np.array_equal(auto[..., 1], img[..., 1])
+
+
+def test_too_narrow_image_uses_exact_kernel(torch_cuda):
+    p = fixca.make_params(blue=1, red=-1, lens_x=3, lens_y=3, interpolation=2)
+    assert fixca.plan(6, 6, 4, 1, p)[0] == 1
+    img = synth.noise_image(3, 6, 6, 4)
+    assert np.array_equal(gpu_run(torch_cuda, img, p, fixca.KERNEL_AUTO), oracle_run(img, p))
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [fixca.KERNEL_EXACT, fixca.KERNEL_FAST])
+def test_row_range_leaves_other_rows_untouched(torch_cuda, interp, kernel):
+    img = synth.noise_image(9, 300, 150, 4)
+    p = fixca.make_params(blue=3.0, red=-2.0, lens_x=10, lens_y=40, interpolation=interp, x_blue=1.5, y_red=-2.25)
+    full = gpu_run(torch_cuda, img, p, kernel)
+    part = gpu_run(torch_cuda, img, p, kernel, y1=41, y2=118, fill=0xAB)
+    assert np.array_equal(part[41:118], full[41:118])
+    assert np.all(part[:41] == 0xAB) and np.all(part[118:] == 0xAB)
+    empty = gpu_run(torch_cuda, img, p, kernel, y1=50, y2=50, fill=0x5A)
+    assert np.all(empty == 0x5A)
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_zero_shift_is_identity(torch_cuda, interp):
+    img = synth.noise_image(7, 520, 130, 3)
+    p = fixca.make_params(lens_x=260, lens_y=65, interpolation=interp)
+    assert np.array_equal(gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST), img)
+
+
+def test_integer_directional_shift_is_a_translation(torch_cuda):
+    """scale exactly 1 and integer shifts: every mode moves whole pixels (edge replicated)."""
+    img = synth.noise_image(17, 400, 100, 4)
+    for interp in (0, 1, 2):
+        p = fixca.make_params(lens_x=200, lens_y=50, interpolation=interp, x_blue=3, y_blue=-2, x_red=-5, y_red=4)
+        out = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST)
+        xs = np.clip(np.arange(400) - 3, 0, 399)
+        ys = np.clip(np.arange(100) + 2, 0, 99)
+        assert np.array_equal(out[..., 2], img[..., 2][ys][:, xs])
+        xs = np.clip(np.arange(400) + 5, 0, 399)
+        ys = np.clip(np.arange(100) - 4, 0, 99)
+        assert np.array_equal(out[..., 0], img[..., 0][ys][:, xs])
+
+
+# ---- the host-pointer entry (what the plug-in calls) --------------------------------
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_host_entry_matches_oracle(torch_cuda, interp):
+    img = synth.noise_image(21, 333, 211, 3)
+    p = fixca.make_params(blue=6.0, red=-2.4, lens_x=58, lens_y=180, interpolation=interp)
+    ref = oracle_run(img, p)
+    dst = np.full_like(img, 0xCD)
+    fixca.fix_ca_region(img, dst, 333, 211, 3, 1, p, 0, 333, 20, 200, True)
+    mx, _ = diff_stats(dst[20:200], ref[20:200])
+    assert mx <= (0 if interp == 0 else TOL_LSB)
+    assert np.all(dst[:20] == 0xCD) and np.all(dst[200:] == 0xCD)
+    fixca.lib.fixca_release_cache()
+
+
+def test_host_entry_exact_env(torch_cuda, monkeypatch):
+    monkeypatch.setenv("FIXCA_EXACT", "1")
+    img = synth.smooth_image(257, 193, 4)
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=28, lens_y=61, interpolation=2)
+    out = fixca.fix_ca_image(img, p)
+    assert md5(out) == "87a23858c4c7bd496ee9f476ca01e606"      # Appendix C: RGBA smooth, P2, cubic
+
+
+def test_device_entry_rejects_bad_calls(torch_cuda):
+    torch = torch_cuda
+    t = torch.zeros(16, 32, 4, dtype=torch.uint8, device="cuda")
+    p = fixca.make_params(blue=1, lens_x=16, lens_y=8)
+    with pytest.raises(fixca.FixCaError) as e:
+        fixca.fix_ca_region(t, t, 32, 16, 4, 1, p, 0, 32, 0, 16)          # aliasing
+    assert e.value.code == fixca.E_INVALID
+    with pytest.raises(fixca.FixCaError) as e:
+        fixca.fix_ca_region(t, torch.empty_like(t), 32, 16, 4, 1, p, 2, 32, 0, 16)
+    assert e.value.code == fixca.E_UNSUPPORTED
+
+
+# ---- batch entry and full-size configurations -------------------------------------------
+
+def test_batch_entry(torch_cuda):
+    torch = torch_cuda
+    p = fixca.make_params(blue=2, red=-2, lens_x=100, lens_y=40, interpolation=2)
+    imgs = [synth.noise_image(100 + i, 320, 96, 4) for i in range(5)]
+    srcs = [torch.from_numpy(a).cuda() for a in imgs]
+    dsts = [torch.empty_like(s) for s in srcs]
+    fixca.fix_ca_batch(srcs, dsts, 320, 96, 4, 1, p)
+    torch.cuda.synchronize()
+    for a, d in zip(imgs, dsts):
+        mx, _ = diff_stats(d.cpu().numpy(), oracle_run(a, p))
+        assert mx <= TOL_LSB
+
+
+@pytest.mark.parametrize("case", [c for c in VEC["full"] if c["width"] == 6000], ids=lambda c: c["name"])
+def test_full_size_configs(torch_cuda, case):
+    """BASELINE.json configs at full size: the fp64 kernel must reproduce the reference's
+    md5; the fast kernel is compared with the (now pinned) fp64 kernel on the GPU."""
+    img = synth.noise_image(case["seed"], case["width"], case["height"], case["channels"])
+    assert md5(img) == case["input_md5"]
+    p = fixca.make_params(interpolation=case["interpolation"], **case["params"])
+    exact = gpu_run(torch_cuda, img, p, fixca.KERNEL_EXACT)
+    assert md5(exact) == case["md5"]
+    fast = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST)
+    mx, n = diff_stats(fast, exact)
+    assert mx <= (0 if case["interpolation"] == 0 else TOL_LSB)
+    assert n <= 0.02 * exact.size
+    assert np.array_equal(fast[..., 1], img[..., 1]) and np.array_equal(fast[..., 3], img[..., 3])
+
+
+def test_directional_8192_config(torch_cuda):
+    """config 4: 8192x8192 RGBA8, pure translation (both scales exactly 1), cubic."""
+    case = [c for c in VEC["full"] if c["width"] == 8192][0]
+    img = synth.noise_image(case["seed"], 8192, 8192, 4)
+    p = fixca.make_params(interpolation=2, **case["params"])
+    exact = gpu_run(torch_cuda, img, p, fixca.KERNEL_EXACT)
+    assert md5(exact) == case["md5"]
+    fast = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST)
+    mx, _ = diff_stats(fast, exact)
+    assert mx <= TOL_LSB
+    # red moves by whole pixels (x 0, y 4): the cubic weights are exactly (0,1,0,0)
+    ys = np.clip(np.arange(8192) - 4, 0, 8191)
+    assert np.array_equal(fast[..., 0], img[..., 0][ys])
+
+
+# ---- the plain-C host layer and its GIMP-less driver ----------------------------------------
+
+def test_cli_end_to_end(torch_cuda, tmp_path):
+    """fixca_cli = load, run()'s argument handling, fix_ca(), save: the path
+    tests/test-fix-ca.scm drives through GIMP, on a crop of the reference's test image
+    with the reference's test parameters (tests/Makefile.am:18)."""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(fixca.LIB_PATH), "fixca_cli")
+    crop = [c for c in real_crops() if c["name"] == "branches_crop"][0]["image"]
+    h, w, _ = crop.shape
+    src, out = tmp_path / "in.ppm", tmp_path / "out.ppm"
+    src.write_bytes(b"P6\n%d %d\n255\n" % (w, h) + crop.tobytes())
+    # as the shipped test passes them: lens 658 1280 read through d_int32 -> centre (0,0)
+    r = subprocess.run([cli, str(src), str(out), "6.0", "-2.4", "658", "1280", "1", "0.0", "0.0", "0.0", "0.0"],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr
+    data = out.read_bytes()
+    hdr = b"P6\n%d %d\n255\n" % (w, h)
+    got = np.frombuffer(data[len(hdr):], np.uint8).reshape(h, w, 3)
+    ref = pyoracle.region(crop, pyoracle.make_params(blue=6.0, red=-2.4, lens_x=0, lens_y=0, interpolation=1))
+    mx, _ = diff_stats(got, ref)
+    assert mx <= TOL_LSB
+    # the centre the script asked for, bit-exact through the fp64 kernel
+    r = subprocess.run([cli, "--lens-as-float", str(src), str(out), "6.0", "-2.4", "58", "180", "2"],
+                       capture_output=True, env=dict(os.environ, FIXCA_EXACT="1"))
+    assert r.returncode == 0, r.stderr
+    got = np.frombuffer(out.read_bytes()[len(hdr):], np.uint8).reshape(h, w, 3)
+    assert md5(got) == [c for c in real_crops() if c["name"] == "branches_crop"][0]["oracle_md5"]["2"]
