@@ -64,6 +64,11 @@ def make_params(blue=0.0, red=0.0, lens_x=-1.0, lens_y=-1.0, interpolation=INTER
 
 
 def _load():
+    # PyTorch (device memory, streams, torch.distributed) ships its own HIP + HSA runtime with
+    # the same SONAME as /opt/rocm's.  Two runtimes in one process cannot both own the GPU, so
+    # torch's copy is mapped first and libfixca_hip.so's NEEDED libamdhip64.so.7 binds to it.
+    # A C host (the plug-in, fixca_cli) has no torch and uses /opt/rocm's runtime.
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise ImportError("libfixca_hip.so not built: run `make -C gimp-fix-ca_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
