@@ -22,18 +22,21 @@ struct FixcaGeom {
 
 /* launch shape chosen by the planner */
 struct FixcaPlan {
-	int kernel;         /* 1 exact, 2 fast-none, 3 fast-interp               */
+	int kernel;         /* 1 exact, 2 fast-none, 3 fast-interp, 4 LDS-ring scan */
 	int oc;             /* output columns per wave (multiple of 4)           */
 	int th;             /* output rows per wave (<= 64)                      */
 	int nstrips;        /* ceil(W / oc)                                      */
 	int nchunks;        /* ceil((y2 - y1) / th)                              */
 	int nwaves;         /* nstrips * nchunks                                 */
-	int nblocks;        /* 256-thread blocks, padded to a multiple of 8      */
+	int nblocks;        /* workgroups, padded to a multiple of 8 (256 threads
+	                       for kernels 2,3; one 64-thread wave for kernel 4)  */
+	int ring;           /* kernel 4: source rows in the LDS ring (power of 2) */
 };
 
 #define FIXCA_K_EXACT   1
 #define FIXCA_K_NONE    2
 #define FIXCA_K_INTERP  3
+#define FIXCA_K_SCAN    4
 
 #define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
 

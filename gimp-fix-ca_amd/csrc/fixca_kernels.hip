@@ -38,68 +38,7 @@
  *
  * No MFMA: this is a gather/warp, not a contraction.  Wave size is 64 throughout.
  */
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "fixca_geom.h"
-
-#define WAVE 64
-#define LANE_PX 4
-
-/* ------------------------------------------------------------------------ */
-/* fp64 helpers: explicit round-to-nearest ops are never contracted to FMA   */
-/* ------------------------------------------------------------------------ */
-
-__device__ __forceinline__ double src_coord(int i, int centre, double s, double shift)
-{
-	/* (i - centre) * s + centre - shift, left to right (fix-ca.c:801, :813) */
-	return __dsub_rn(__dadd_rn(__dmul_rn((double)(i - centre), s), (double)centre), shift);
-}
-
-__device__ __forceinline__ int rnd_half_away(double d)      /* fix-ca.c:776-789 */
-{
-	if (d >= 0) {
-		if (d > 2147483647.0) return 2147483647;
-		return (int)__dadd_rn(d, 0.5);
-	}
-	if (d < -2147483648.0) return (-2147483647 - 1);
-	return -((int)__dsub_rn(0.5, d));
-}
-
-__device__ __forceinline__ int map_int(int i, int centre, int size, double s, double shift)
-{
-	int j = rnd_half_away(src_coord(i, centre, s, shift));   /* fix-ca.c:799-809 */
-	if (j <= 0) return 0;
-	if (j >= size) return size - 1;
-	return j;
-}
-
-__device__ __forceinline__ double map_dbl(int i, int centre, int size, double s, double shift)
-{
-	double d = src_coord(i, centre, s, shift);               /* fix-ca.c:811-820 */
-	if (d <= 0.0) return 0.0;
-	if (d >= (double)(size - 1)) return (double)(size - 1);
-	return d;
-}
-
-__device__ __forceinline__ double clip01(double d)
-{
-	if (d <= 0.0) return 0.0;
-	if (d >= 1.0) return 1.0;
-	return d;
-}
-
-/* Catmull-Rom in the reference's operation order (fix-ca.c:905-907, :916-918) */
-__device__ __forceinline__ double cr_exact(double a, double b, double c, double d, double t)
-{
-	double k3 = __dadd_rn(__dsub_rn(__dadd_rn(-a, __dmul_rn(3.0, b)), __dmul_rn(3.0, c)), d);
-	double k2 = __dsub_rn(__dadd_rn(__dsub_rn(__dmul_rn(2.0, a), __dmul_rn(5.0, b)), __dmul_rn(4.0, c)), d);
-	double k1 = __dadd_rn(-a, c);
-	double r = __dadd_rn(__dmul_rn(k3, t), k2);
-	r = __dadd_rn(__dmul_rn(r, t), k1);
-	r = __dadd_rn(__dmul_rn(r, t), __dadd_rn(b, b));
-	return __ddiv_rn(r, 2.0);
-}
+#include "fixca_device.h"
 
 /* ------------------------------------------------------------------------ */
 /* k_exact: one thread per pixel, fp64, bit-exact                            */
@@ -181,13 +120,6 @@ k_exact(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g)
 /* shared pieces of the fast kernels                                         */
 /* ------------------------------------------------------------------------ */
 
-/* v_perm_b32: result byte i = byte sel[i] of the 64-bit value {hi, lo}
- * (selector 0-3 -> lo bytes 0-3, 4-7 -> hi bytes 0-3). */
-__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
-{
-	return __builtin_amdgcn_perm(hi, lo, sel);
-}
-
 /* 4 pixels of an interleaved row, 16 B (RGBA) or 12 B (RGB); w[3] unused for RGB.
  * Pixel addresses are only 4-byte (RGBA) / 1-byte (RGB) aligned. */
 struct Px4 { uint32_t w[4]; };
@@ -254,13 +186,6 @@ __device__ __forceinline__ Px4 merge_rb(const Px4 &idt, uint32_t rq, uint32_t bq
 		o.w[3] = 0;
 	}
 	return o;
-}
-
-/* XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so
- * give every XCD a contiguous range of tiles; nblocks is a multiple of 8. */
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks)
-{
-	return (bid & 7) * (nblocks >> 3) + (bid >> 3);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -331,28 +256,6 @@ k_none(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 /* ------------------------------------------------------------------------ */
 /* k_interp: LINEAR (TAPS 2) / CUBIC (TAPS 4) row scan                       */
 /* ------------------------------------------------------------------------ */
-
-/* Catmull-Rom tap weights at parameter t: value = sum w[j] * p[j], p = taps -1,0,+1,+2.
- * Same polynomial as fix-ca.c:905-907 regrouped by sample; computed in fp64, used in fp32. */
-__device__ __forceinline__ void cr_weights(double t, float w[4])
-{
-	double t2 = t * t, t3 = t2 * t;
-	w[0] = (float)((-t3 + 2.0 * t2 - t) * 0.5);
-	w[1] = (float)((3.0 * t3 - 5.0 * t2 + 2.0) * 0.5);
-	w[2] = (float)((-3.0 * t3 + 4.0 * t2 + t) * 0.5);
-	w[3] = (float)((t3 - t2) * 0.5);
-}
-
-template <int TAPS>
-__device__ __forceinline__ void tap_weights(double t, float w[TAPS])
-{
-	if (TAPS == 4) {
-		cr_weights(t, w);
-	} else {
-		w[0] = (float)(1.0 - t);
-		w[1] = (float)t;
-	}
-}
 
 /* this channel's byte of 4 loaded pixels, permuted by the lane's edge-clamp selector */
 template <int BPP>
@@ -582,6 +485,8 @@ k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 /* launchers (called from fixca_abi.hip)                                     */
 /* ------------------------------------------------------------------------ */
 
+extern "C" hipError_t fixca_launch_scan(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+
 extern "C" hipError_t
 fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
@@ -609,6 +514,8 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 			else             hipLaunchKernelGGL((k_interp<3, 4>), dim3(pl->nblocks), dim3(256), 0, stream, s, d, *g, *pl);
 		}
 		break;
+	case FIXCA_K_SCAN:
+		return fixca_launch_scan(d_src, d_dst, g, pl, stream);
 	default:
 		return hipErrorInvalidValue;
 	}

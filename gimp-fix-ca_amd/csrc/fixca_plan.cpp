@@ -29,6 +29,26 @@ static double h_map_dbl(int i, int centre, int size, double s, double shift)
 	return d;
 }
 
+static int h_rnd(double d)                                /* fix-ca.c:776-789 */
+{
+	if (d >= 0) {
+		if (d > INT_MAX) return INT_MAX;
+		return (int)(d + 0.5);
+	}
+	if (d < INT_MIN) return INT_MIN;
+	return -((int)(0.5 - d));
+}
+
+static int h_map_int(int i, int centre, int size, double s, double shift)
+{
+	int j = h_rnd(h_coord(i, centre, s, shift));
+	if (j <= 0) return 0;
+	if (j >= size) return size - 1;
+	return j;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
 static int trunc_to_int(double d)
 {
 	if (!(d > (double)INT_MIN)) return INT_MIN + 1;       /* also NaN */
@@ -115,6 +135,88 @@ static bool interp_fits(const FixcaGeom *g, int oc, int taps)
 	return true;
 }
 
+
+/* ---- plan for the LDS-ring scan kernel (fixca_scan.hip) -------------------------- */
+
+/* does every strip's union window (identity columns + red taps + blue taps) fit 256 columns? */
+static bool scan_cols_fit(const FixcaGeom *g, int oc, int taps)
+{
+	const int back = (taps == 4) ? 1 : 0, W = g->W;
+	const int nstrips = (W + oc - 1) / oc;
+	for (int st = 0; st < nstrips; ++st) {
+		int X0 = st * oc;
+		if (X0 > W - oc) X0 = W - oc;
+		int lo = X0, hi = X0 + oc - 1;
+		for (int c = 0; c < 2; ++c) {
+			int a, b;
+			if (taps == 0) {
+				a = h_map_int(X0, g->xc, W, g->s[c], g->xs[c]);
+				b = h_map_int(X0 + oc - 1, g->xc, W, g->s[c], g->xs[c]);
+			} else {
+				a = clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1);
+				b = clampi((int)floor(h_map_dbl(X0 + oc - 1, g->xc, W, g->s[c], g->xs[c])) - back + taps - 1, 0, W - 1);
+			}
+			if (a < lo) lo = a;
+			if (b > hi) hi = b;
+		}
+		int U0 = lo & ~3;
+		if (U0 > W - FIXCA_WAVE_COLS) U0 = W - FIXCA_WAVE_COLS;
+		if (hi > U0 + FIXCA_WAVE_COLS - 1) return false;
+	}
+	return true;
+}
+
+/* most source rows any output row keeps alive at once (identity row + both windows) */
+static int scan_row_span(const FixcaGeom *g, int taps)
+{
+	const int back = (taps == 4) ? 1 : 0, H = g->H;
+	int span = 1;
+	for (int y = g->y1; y < g->y2; ++y) {
+		int keep = y, need = y;
+		for (int c = 0; c < 2; ++c) {
+			int a, b;
+			if (taps == 0) {
+				a = b = h_map_int(y, g->yc, H, g->s[c], g->ys[c]);
+			} else {
+				int y0 = (int)floor(h_map_dbl(y, g->yc, H, g->s[c], g->ys[c]));
+				a = clampi(y0 - back, 0, H - 1);
+				b = clampi(y0 - back + taps - 1, 0, H - 1);
+			}
+			if (a < keep) keep = a;
+			if (b > need) need = b;
+		}
+		if (need - keep + 1 > span) span = need - keep + 1;
+	}
+	return span;
+}
+
+static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
+{
+	if (g->bpp != 4 || (g->W & 3) || g->W < FIXCA_WAVE_COLS) return false;
+	if ((long long)g->W * g->H * 4 >= (1LL << 40)) return false;
+	const int taps = (g->interp == 0) ? 0 : (g->interp == 1 ? 2 : 4);
+	const int span = scan_row_span(g, taps);
+	int ring = env_int("FIXCA_RING", 0, 0, 32);
+	if (ring == 0) ring = (span + 4 <= 8) ? 8 : (span + 4 <= 16) ? 16 : 32;
+	if ((ring & (ring - 1)) || span + 2 > ring) return false;
+	int oc_max = env_int("FIXCA_OC", 252, 64, 252) & ~3;
+	for (int oc = oc_max; oc >= 128; oc -= 4) {
+		if (!scan_cols_fit(g, oc, taps)) continue;
+		pl->kernel = FIXCA_K_SCAN;
+		pl->oc = oc;
+		pl->th = env_int("FIXCA_TH", 32, 1, 1 << 20);
+		pl->ring = ring;
+		int rows = g->y2 - g->y1;
+		pl->nstrips = (g->W + oc - 1) / oc;
+		pl->nchunks = (rows + pl->th - 1) / pl->th;
+		if (pl->nchunks < 1) pl->nchunks = 1;
+		pl->nwaves = pl->nstrips * pl->nchunks;
+		pl->nblocks = (pl->nwaves + 7) & ~7;
+		return true;
+	}
+	return false;
+}
+
 static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
 {
 	int rows = g->y2 - g->y1;
@@ -132,7 +234,11 @@ int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	pl->kernel = FIXCA_K_EXACT;
 	if (want == FIXCA_KERNEL_EXACT) return FIXCA_OK;
 
-	/* the fast kernels load 4 pixels at a time and index rows/columns with int */
+	if (!getenv("FIXCA_NO_SCAN") && plan_scan(g, pl)) return FIXCA_OK;
+	memset(pl, 0, sizeof *pl);
+	pl->kernel = FIXCA_K_EXACT;
+
+	/* the register-window kernels load 4 pixels at a time and index rows/columns with int */
 	const bool size_ok = g->W >= 8 && (long long)g->W * g->H * g->bpp < (1LL << 40);
 	const int th = env_int("FIXCA_TH", 32, 1, 64);
 
@@ -163,11 +269,14 @@ int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n)
 {
-	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp" };
+	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan" };
 	static const char *in[] = { "none", "linear", "cubic" };
 	if (!buf || !n) return;
 	if (pl->kernel == FIXCA_K_EXACT)
 		snprintf(buf, n, "%s %s bpp=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, (g->W + 255) / 256, g->y2 - g->y1);
+	else if (pl->kernel == FIXCA_K_SCAN)
+		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
+		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);
 	else
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d strips=%d chunks=%d waves=%d blocks=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->nblocks);
