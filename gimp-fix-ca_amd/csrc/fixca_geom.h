@@ -30,13 +30,16 @@ struct FixcaPlan {
 	int nwaves;         /* nstrips * nchunks                                 */
 	int nblocks;        /* workgroups, padded to a multiple of 8 (256 threads
 	                       for kernels 2,3; one 64-thread wave for kernel 4)  */
-	int ring;           /* kernel 4: source rows in the LDS ring (power of 2) */
+	int ring;           /* kernels 4,5: source rows in the LDS ring            */
+	int ablate;         /* timing experiments only (FIXCA_ABLATE): 1 = skip the filter
+	                       arithmetic, 2 = skip the counted waits; results are wrong */
 };
 
 #define FIXCA_K_EXACT   1
 #define FIXCA_K_NONE    2
 #define FIXCA_K_INTERP  3
 #define FIXCA_K_SCAN    4
+#define FIXCA_K_SCANW   5   /* scan with the ring shared by the 4 waves of a workgroup */
 
 #define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
 

@@ -196,16 +196,25 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 	if ((long long)g->W * g->H * 4 >= (1LL << 40)) return false;
 	const int taps = (g->interp == 0) ? 0 : (g->interp == 1 ? 2 : 4);
 	const int span = scan_row_span(g, taps);
-	int ring = env_int("FIXCA_RING", 0, 0, 32);
-	if (ring == 0) ring = (span + 4 <= 8) ? 8 : (span + 4 <= 16) ? 16 : 32;
-	if ((ring & (ring - 1)) || span + 2 > ring) return false;
+	const bool shared = getenv("FIXCA_SCANW") != NULL;  /* 4-wave shared-ring variant only on request (it is not faster yet) */
+	int ring = env_int("FIXCA_RING", 0, 0, 64);
+	if (shared) {
+		/* a group of 4 rows keeps span + 3 rows alive, the previous group 4 more, plus 8 in flight */
+		if (ring == 0) ring = (span + 3 + 4 + 8 + 3) & ~3;
+		if (ring > 64 || span + 3 + 4 + 2 > ring) return false;
+	} else {
+		/* a block of 4 output rows keeps span + 3 rows alive; leave >= 4 slots for rows in flight */
+		if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : 32;
+		if ((ring & (ring - 1)) || span + 5 > ring) return false;
+	}
 	int oc_max = env_int("FIXCA_OC", 252, 64, 252) & ~3;
 	for (int oc = oc_max; oc >= 128; oc -= 4) {
 		if (!scan_cols_fit(g, oc, taps)) continue;
-		pl->kernel = FIXCA_K_SCAN;
+		pl->kernel = shared ? FIXCA_K_SCANW : FIXCA_K_SCAN;
 		pl->oc = oc;
-		pl->th = env_int("FIXCA_TH", 32, 1, 1 << 20);
+		pl->th = env_int("FIXCA_TH", 64, 1, 1 << 20);
 		pl->ring = ring;
+		pl->ablate = env_int("FIXCA_ABLATE", 0, 0, 3);
 		int rows = g->y2 - g->y1;
 		pl->nstrips = (g->W + oc - 1) / oc;
 		pl->nchunks = (rows + pl->th - 1) / pl->th;
@@ -269,12 +278,12 @@ int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n)
 {
-	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan" };
+	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "scanw" };
 	static const char *in[] = { "none", "linear", "cubic" };
 	if (!buf || !n) return;
 	if (pl->kernel == FIXCA_K_EXACT)
 		snprintf(buf, n, "%s %s bpp=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, (g->W + 255) / 256, g->y2 - g->y1);
-	else if (pl->kernel == FIXCA_K_SCAN)
+	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);
 	else

@@ -275,3 +275,50 @@ def test_cli_end_to_end(torch_cuda, tmp_path):
     assert r.returncode == 0, r.stderr
     got = np.frombuffer(out.read_bytes()[len(hdr):], np.uint8).reshape(h, w, 3)
     assert md5(got) == [c for c in real_crops() if c["name"] == "branches_crop"][0]["oracle_md5"]["2"]
+
+
+# ---- every fast kernel variant on the same inputs ------------------------------------------------
+
+VARIANTS = {
+    "scan": {},                                   # LDS-ring scan, one wave per strip (default for RGBA, W % 4 == 0)
+    "scan-th7": {"FIXCA_TH": "7"},                # short chunks: generic rows dominate, odd tails
+    "scan-th200": {"FIXCA_TH": "200"},            # chunks longer than one 64-row table
+    "scanw": {"FIXCA_SCANW": "1"},                # ring shared by the 4 waves of a workgroup
+    "scanw-th13": {"FIXCA_SCANW": "1", "FIXCA_TH": "13"},
+    "regwin": {"FIXCA_NO_SCAN": "1"},             # register-window kernels
+}
+SCAN_SHAPES = [(256, 70), (260, 33), (512, 300), (1000, 50), (1024, 257)]
+SCAN_PARAMS = [
+    dict(blue=2.0, red=-2.0, lens_x=0.1, lens_y=0.3),
+    dict(blue=-3.3, red=4.7, lens_x=-1, lens_y=-1, x_blue=2.5, x_red=-1.25, y_blue=.75, y_red=-3),
+    dict(lens_x=0.5, lens_y=0.5, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0),
+    dict(blue=12.0, red=-9.0, lens_x=0.7, lens_y=0.2, x_blue=-6, x_red=5.5, y_blue=4, y_red=-4.25),
+]
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("shape", SCAN_SHAPES, ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("pi", range(len(SCAN_PARAMS)))
+def test_kernel_variants_agree_with_oracle(torch_cuda, monkeypatch, variant, shape, pi):
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    w, h = shape
+    img = synth.noise_image(4000 + w + h + pi, w, h, 4)
+    for interp in (0, 1, 2):
+        p = fixca.make_params(interpolation=interp, **_scaled(SCAN_PARAMS[pi], w, h))
+        kid, desc = fixca.plan(w, h, 4, 1, p, kernel=fixca.KERNEL_FAST)
+        if variant.startswith("scanw"):
+            assert kid in (3, 5), desc
+        elif variant.startswith("scan"):
+            assert kid in (3, 4), desc
+        else:
+            assert kid in (2, 3), desc
+        ref = oracle_run(img, p)
+        out = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST)
+        mx, n = diff_stats(out, ref)
+        assert mx <= (0 if interp == 0 else TOL_LSB), (desc, mx, n)
+        assert n <= 0.02 * ref.size
+        assert np.array_equal(out[..., 1], img[..., 1]) and np.array_equal(out[..., 3], img[..., 3])
+        part = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST, y1=h // 3, y2=h - 5, fill=0x77)
+        assert np.array_equal(part[h // 3:h - 5], out[h // 3:h - 5])
+        assert np.all(part[:h // 3] == 0x77) and np.all(part[h - 5:] == 0x77)

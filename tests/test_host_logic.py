@@ -31,7 +31,8 @@ def _params(kw, w, h, interp):
 @pytest.mark.parametrize("size", [(257, 193, 4), (300, 70, 3), (64, 40, 4), (1000, 50, 4)])
 @pytest.mark.parametrize("pset", range(len(PSETS)))
 @pytest.mark.parametrize("interp", [1, 2])
-def test_model_within_one_lsb(size, pset, interp):
+def test_model_within_one_lsb(size, pset, interp, monkeypatch):
+    monkeypatch.setenv("FIXCA_NO_SCAN", "1")       # the model describes the register-window kernel
     w, h, c = size
     kw = _params(PSETS[pset], w, h, interp)
     p = fixca.make_params(interpolation=interp, **kw)

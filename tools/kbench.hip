@@ -121,12 +121,16 @@ int main(int argc, char **argv)
 
 	FixCaParams p; memset(&p, 0, sizeof p);
 	p.blue = 2.0; p.red = -2.0; p.lens_x = 658; p.lens_y = 1280;
+	const char *abl = getenv("KB_ABLATE") ? getenv("KB_ABLATE") : "0";
 	const char *ths = getenv("KB_TH") ? getenv("KB_TH") : "8 16 32 64";
 	const char *ocs = getenv("KB_OC") ? getenv("KB_OC") : "252";
 	for (int interp : {2, 1, 0}) {
 		p.interpolation = interp;
-		char *tl = strdup(ths);
-		for (char *t = strtok(tl, " "); t; t = strtok(NULL, " ")) {
+		char *al = strdup(abl), *asave;
+		for (char *ab = strtok_r(al, " ", &asave); ab; ab = strtok_r(NULL, " ", &asave)) {
+		setenv("FIXCA_ABLATE", ab, 1);
+		char *tl = strdup(ths), *tsave;
+		for (char *t = strtok_r(tl, " ", &tsave); t; t = strtok_r(NULL, " ", &tsave)) {
 			char *ol = strdup(ocs), *save;
 			for (char *o = strtok_r(ol, " ", &save); o; o = strtok_r(NULL, " ", &save)) {
 				setenv("FIXCA_TH", t, 1); setenv("FIXCA_OC", o, 1);
@@ -135,12 +139,15 @@ int main(int argc, char **argv)
 				double us = time_it(L, [&](int i) {
 					if (fixca_region_device(src4[i % NP], dst4[i % NP], W, H, 4, 1, &p, 0, W, 0, H, 1, FIXCA_KERNEL_FAST, NULL)) { printf("err %s\n", fixca_last_error()); exit(1); }
 				});
-				report(desc, us);
+				char d2[300]; snprintf(d2, 300, "[abl %s] %s", ab, desc);
+				report(d2, us);
 				if (interp == 0) break;
 			}
 			free(ol);
 		}
 		free(tl);
+		}
+		free(al);
 	}
 	return 0;
 }
