@@ -22,7 +22,7 @@ struct FixcaGeom {
 
 /* launch shape chosen by the planner */
 struct FixcaPlan {
-	int kernel;         /* 1 exact, 2 fast-none, 3 fast-interp, 4 LDS-ring scan */
+	int kernel;         /* FIXCA_K_* below */
 	int oc;             /* output columns per wave (multiple of 4)           */
 	int th;             /* output rows per wave (<= 64)                      */
 	int nstrips;        /* ceil(W / oc)                                      */
@@ -40,6 +40,7 @@ struct FixcaPlan {
 #define FIXCA_K_INTERP  3
 #define FIXCA_K_SCAN    4
 #define FIXCA_K_SCANW   5   /* scan with the ring shared by the 4 waves of a workgroup */
+#define FIXCA_K_ROLL    6   /* LDS ring, horizontal-first rolling window (fixca_roll.hip) */
 
 #define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
 

@@ -226,6 +226,130 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 	return false;
 }
 
+
+/* ---- plan for the row-rolling kernel (fixca_roll.hip) ----------------------------- */
+
+/* tap weights exactly as the kernels compute them (fixca_device.h tap_weights: fp64 polynomial,
+ * rounded to fp32); only "is it zero" matters here */
+static void h_tap_weights(double t, int taps, float *w)
+{
+	if (taps == 4) {
+		double t2 = t * t, t3 = t2 * t;
+		w[0] = (float)((-t3 + 2.0 * t2 - t) * 0.5);
+		w[1] = (float)((3.0 * t3 - 5.0 * t2 + 2.0) * 0.5);
+		w[2] = (float)((-3.0 * t3 + 4.0 * t2 + t) * 0.5);
+		w[3] = (float)((t3 - t2) * 0.5);
+	} else {
+		w[0] = (float)(1.0 - t);
+		w[1] = (float)t;
+	}
+}
+
+/* first and last tap column WITH WEIGHT of output column x, clamped as the reference clamps
+ * them (fix-ca.c:1170-1177 linear, :1270-1298 cubic).  A coordinate clamped to the image edge
+ * has fraction 0 and all its weight on one column. */
+static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int *last)
+{
+	const int W = g->W;
+	const double xd = h_map_dbl(x, g->xc, W, g->s[c], g->xs[c]);
+	const int x0 = (int)floor(xd);
+	int col[4];
+	float w[4];
+	h_tap_weights(xd - (double)x0, taps, w);
+	if (taps == 4) {
+		col[0] = x0 - 1 > 0 ? x0 - 1 : 0;
+		col[1] = x0;
+		col[2] = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
+		col[3] = col[2] + 1 < W - 1 ? col[2] + 1 : W - 1;
+	} else {
+		col[0] = x0;
+		col[1] = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
+	}
+	*first = INT_MAX;
+	*last = INT_MIN;
+	for (int t = 0; t < taps; ++t)
+		if (w[t] != 0.f) {
+			if (col[t] < *first) *first = col[t];
+			if (col[t] > *last) *last = col[t];
+		}
+}
+
+/* Every strip must satisfy what k_roll assumes: with m = min over the strip of (tap column - x),
+ * every tap with weight lands on pixel i + j of the lane's 8, 0 <= j <= 4; the lane windows
+ * start at most 4 px before and end at most 16 px past the 256-column ring row; every column
+ * that carries weight is inside the ring row. */
+static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
+{
+	const int back = (taps == 4) ? 1 : 0, W = g->W;
+	const int nstrips = (W + oc - 1) / oc;
+	for (int st = 0; st < nstrips; ++st) {
+		int X0 = st * oc;
+		if (X0 > W - oc) X0 = W - oc;
+		int lo = X0, hi = X0 + oc - 1, m[2];
+		for (int c = 0; c < 2; ++c) {
+			int a = clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1);
+			if (a < lo) lo = a;
+		}
+		for (int c = 0; c < 2; ++c) {
+			int mn = INT_MAX, mx = INT_MIN;
+			for (int x = X0; x < X0 + oc; ++x) {
+				int f, l;
+				tap_span(g, c, x, taps, &f, &l);
+				if (f - x < mn) mn = f - x;
+				if (l - x > mx) mx = l - x;
+				if (l > hi) hi = l;
+				if (f < lo) return false;               /* the window start assumes the first column needs the lowest tap */
+			}
+			if (mx - mn > 4) return false;
+			m[c] = mn;
+		}
+		int U0 = lo & ~3;
+		if (U0 > W - FIXCA_WAVE_COLS) U0 = W - FIXCA_WAVE_COLS;
+		if (hi > U0 + FIXCA_WAVE_COLS - 1) return false;
+		for (int c = 0; c < 2; ++c) {
+			const int P = X0 + m[c] - U0;
+			if (P < -4 || P > 16) return false;
+		}
+	}
+	return true;
+}
+
+static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
+{
+	if (g->bpp != 4 || (g->W & 3) || g->W < FIXCA_WAVE_COLS || g->interp == 0) return false;
+	if ((long long)g->W * g->H * 4 > (1LL << 31)) return false;            /* 32-bit buffer offsets, see k_roll */
+	const int taps = (g->interp == 1) ? 2 : 4;
+	const int span = scan_row_span(g, taps);
+	/* a block of 4 output rows keeps span + 3 rows alive; leave >= 2 slots for rows in flight */
+	int ring = env_int("FIXCA_RING", 0, 0, 32);
+	if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : 32;
+	if ((ring & (ring - 1)) || span + 5 > ring) return false;
+	int oc_max = env_int("FIXCA_OC", 252, 64, 252) & ~3;
+	for (int oc = oc_max; oc >= 128; oc -= 4) {
+		if (!roll_cols_fit(g, oc, taps)) continue;
+		const int rows = g->y2 - g->y1;
+		pl->kernel = FIXCA_K_ROLL;
+		pl->ablate = env_int("FIXCA_ABLATE", 0, 0, 15);
+		pl->oc = oc;
+		pl->ring = ring;
+		pl->nstrips = (g->W + oc - 1) / oc;
+		/* one round of waves: as many rows per wave as it takes for every wave to be resident
+		 * at once (LDS: ring + pads per wave; 160 KB per CU, 256 CUs) */
+		const int per_cu = (160 * 1024) / (ring * 1024 + 512);
+		int max_chunks = per_cu * 256 / pl->nstrips;
+		if (max_chunks < 1) max_chunks = 1;
+		int th = (rows + max_chunks - 1) / max_chunks;
+		if (th < 16) th = 16;
+		pl->th = env_int("FIXCA_TH", th, 1, 1 << 20);
+		pl->nchunks = (rows + pl->th - 1) / pl->th;
+		if (pl->nchunks < 1) pl->nchunks = 1;
+		pl->nwaves = pl->nstrips * pl->nchunks;
+		pl->nblocks = (pl->nwaves + 7) & ~7;
+		return true;
+	}
+	return false;
+}
+
 static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
 {
 	int rows = g->y2 - g->y1;
@@ -236,13 +360,54 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
 	pl->nblocks = ((pl->nwaves + 3) / 4 + 7) & ~7;
 }
 
+static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl);
+
+/* The planner walks every column and row of the image (tens of microseconds for 6000x4000,
+ * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
+ * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
+ * environment variables are part of the key so that a changed variable re-plans. */
+static const char *const plan_env[] = { "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
+                                        "FIXCA_TH", "FIXCA_ABLATE" };
+
+static void env_signature(char *buf, size_t n)
+{
+	size_t o = 0;
+	for (size_t i = 0; i < sizeof plan_env / sizeof plan_env[0] && o + 1 < n; ++i) {
+		const char *e = getenv(plan_env[i]);
+		o += (size_t)snprintf(buf + o, n - o, "%s;", e ? e : "-");
+	}
+	if (o >= n) buf[n - 1] = 0;
+}
+
 int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
+{
+	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; char env[160]; FixcaPlan pl; } last;
+	char env[160];
+	env_signature(env, sizeof env);
+	if (last.valid && last.flags == flags && memcmp(&last.g, g, sizeof *g) == 0 && strcmp(last.env, env) == 0) {
+		*pl = last.pl;
+		return FIXCA_OK;
+	}
+	int rc = make_plan_uncached(g, flags, pl);
+	if (rc == FIXCA_OK) {
+		last.valid = true;
+		last.g = *g;
+		last.flags = flags;
+		memcpy(last.env, env, sizeof env);
+		last.pl = *pl;
+	}
+	return rc;
+}
+
+static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
 	const unsigned want = flags & FIXCA_KERNEL_MASK;
 	memset(pl, 0, sizeof *pl);
 	pl->kernel = FIXCA_K_EXACT;
 	if (want == FIXCA_KERNEL_EXACT) return FIXCA_OK;
 
+	if (!getenv("FIXCA_NO_ROLL") && plan_roll(g, pl)) return FIXCA_OK;
+	memset(pl, 0, sizeof *pl);
 	if (!getenv("FIXCA_NO_SCAN") && plan_scan(g, pl)) return FIXCA_OK;
 	memset(pl, 0, sizeof *pl);
 	pl->kernel = FIXCA_K_EXACT;
@@ -278,12 +443,12 @@ int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n)
 {
-	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "scanw" };
+	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "scanw", "roll" };
 	static const char *in[] = { "none", "linear", "cubic" };
 	if (!buf || !n) return;
 	if (pl->kernel == FIXCA_K_EXACT)
 		snprintf(buf, n, "%s %s bpp=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, (g->W + 255) / 256, g->y2 - g->y1);
-	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW)
+	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);
 	else

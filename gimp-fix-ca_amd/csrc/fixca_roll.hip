@@ -1,0 +1,481 @@
+/*
+ * fixca_roll.hip — the row-rolling kernel (RGBA8, LINEAR / CUBIC): the main kernel of the path.
+ *
+ * Same data movement as the LDS-ring scan kernel (fixca_scan.hip):
+ *
+ *   HBM/L2 --LDS-DMA--> ring of K source rows in LDS --> registers --> HBM
+ *
+ * one wave (a 64-thread workgroup) owns `oc` output columns x `th` output rows, streams every
+ * source row of its 256-column window into LDS once with global_load_lds_dwordx4 and waits for
+ * exactly the row it needs with a counted s_waitcnt vmcnt.  What differs is the filter:
+ *
+ *  - HORIZONTAL FIRST, straight from the ring, no exchange through LDS.  The map is
+ *    x' = (x - xc)*s + xc - shift with s within a fraction of a percent of 1, so over one strip the
+ *    first tap of output column x sits at x + m or x + m + 1 for one strip constant m.  Lane L
+ *    reads the 4 ring pixels [P + 4L, P + 4L + 4) (one 16-byte LDS read per channel and source
+ *    row; P = m relative to the window) and takes the next 4 from lane L + 1 with a DPP
+ *    wave-shift folded into the byte->float conversion (v_cvt_f32_ubyteN_dpp wave_shl:1): 8 pixels
+ *    in registers, no data crosses LDS a second time.  The "+1" steps, and the reference's edge
+ *    clamping (fix-ca.c:1270-1298), are folded into the lane's tap weights: output i uses
+ *    pixels i .. i+4 of the 8 with 5 weights of which at most T are non-zero (clamped taps add
+ *    their weights on the clamped column).  Waves whose strip has no step and touches no edge
+ *    (most of them) run a T-tap loop instead.
+ *  - The horizontally filtered row of each channel (4 floats per lane, red and blue packed in
+ *    f32x2 for v_pk_fma_f32) enters a rolling window of T rows in registers; the vertical
+ *    filter (fix-ca.c:911-920) is T packed FMAs per pixel with wave-uniform weights.
+ *    This is the reference's own order: cubicY across columns, then cubicX across rows.
+ *  - Per-row values (source rows, vertical weights, ring bounds) are computed once per wave,
+ *    one output row per lane, and broadcast with v_readlane.
+ *
+ * fp32 sample arithmetic on fp64 coordinates: within 1 LSB of the reference; green and alpha
+ * are copied bit-exactly.  Per output row and lane: 3 LDS reads, ~60 vector ALU operations,
+ * one 16-byte store; no barrier, no LDS write by the wave itself.
+ *
+ * The planner (fixca_plan.cpp, plan_roll) selects this kernel when W % 4 == 0, W >= 256, every
+ * strip's union window fits 256 columns, its tap offsets drift by at most one column and the
+ * rows alive at once fit the ring; everything else goes to the kernels in fixca_scan.hip /
+ * fixca_kernels.hip.
+ */
+#include "fixca_device.h"
+#include <type_traits>
+
+typedef float        f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+#define RING_ROW    1024                /* bytes per ring row: 256 px x 4 B                      */
+#define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
+#define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
+#define RDEPTH      6                   /* source rows kept in flight beyond the newest row in use */
+
+/* v_cvt_pk_u8_f32 rounds to nearest EVEN; the reference rounds half away from zero (set_pixel,
+ * fix-ca.c:752): ties must go up, which a bias of 2^-13 (8 fp32 ulps at 255) does. */
+#define ROUND_BIAS 0.0001220703125f
+
+template <int N> __device__ __forceinline__ void roll_wait_vm()
+{
+	asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ int rclampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }
+__device__ __forceinline__ int rrl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rrlf(float v, int lane)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+/* the dword lane L + 1 holds (0 in lane 63): DPP wave_shl:1 */
+__device__ __forceinline__ uint32_t next_lane(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+template <int TAPS>
+struct RollState {
+	static constexpr int T = TAPS;
+	int      lane;
+	int      abl;               /* timing experiments (FIXCA_ABLATE): 1 no DPP, 2 aligned window reads, 4 no vertical weights broadcast */
+	bool     active;
+	int      tap[2];            /* byte offset (may be negative) of my 4-pixel window in a ring row */
+	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
+	/* row table: lane j describes output row Y0 + 64*blk + j */
+	int      t_rb[2], t_keep, t_need;
+	float    t_wy[2][T];
+	unsigned long long regmask; /* bit j: both windows of row j slide down by exactly one unclamped row */
+	/* ring */
+	uint8_t *ring;
+	int      KM, H;
+	int      ld;                /* highest source row issued                                   */
+	int      lastneed;          /* highest source row this wave ever needs                     */
+	int      seq, seqtab;       /* loads issued; lane s: seq of the load in slot s              */
+	/* global memory goes through buffer descriptors: the per-lane part of an address is a
+	 * constant 32-bit offset, the row part a scalar, and a lane that must not store gets an
+	 * offset outside the buffer (dropped by the range check) instead of a branch */
+	rsrc_t   rs_src, rs_dst;
+	uint32_t vo_ld;             /* my byte offset inside a source row segment                   */
+	uint32_t vo_st;             /* my byte offset inside an output row, ~0 if I produce nothing */
+	uint32_t so_ld;             /* byte offset of source row ld + 1                             */
+	uint32_t so_st;             /* byte offset of the next output row                           */
+	uint32_t pitch;
+	const uint8_t *gsrc; uint8_t *gdst;   /* experiments: flat-address forms of the same accesses */
+	/* the newest T-1 horizontally filtered rows, (red, blue) of my 4 output columns */
+	f32x2    hist[T - 1][4];
+};
+
+template <int TAPS>
+__device__ __forceinline__ void roll_issue(RollState<TAPS> &st)
+{
+	++st.ld;
+	const int slot = st.ld & st.KM;
+	if (st.abl & 4)
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st.gsrc + st.so_ld + st.vo_ld),
+		                                 (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW), 16, 0, 0);
+	else
+#if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW),
+	                                         16, st.vo_ld, st.so_ld, 0, 0);
+#endif
+	st.so_ld += st.pitch;
+	st.seqtab = (st.lane == slot) ? st.seq : st.seqtab;     /* v_writelane by hand */
+	++st.seq;
+}
+
+/* keep RDEPTH rows in flight beyond `need` (within the ring's capacity), then wait until row
+ * `need` has landed.
+ * vmcnt counts loads and stores together, and on gfx9-family hardware loads complete in order
+ * among loads and stores among stores, but NOT across the two kinds (a young store may be
+ * acknowledged before an old load has landed; seen on MI355X as partially landed ring rows).
+ * So the wait may only rely on loads: with L loads younger than the one needed, "at most L
+ * operations outstanding" implies "at most L loads outstanding", which implies the needed
+ * load is done.  seq therefore counts loads only, and stores in flight merely make the wait
+ * stricter, never wrong. */
+template <int TAPS>
+__device__ __forceinline__ void roll_fetch(RollState<TAPS> &st, int keep, int need)
+{
+	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
+	while (st.ld < target) roll_issue(st);
+	const int younger = st.seq - rrl(st.seqtab, need & st.KM) - 1;
+	if (st.abl & 1) roll_wait_vm<0>();
+	else if (younger >= 6) roll_wait_vm<6>();
+	else if (younger >= 4) roll_wait_vm<4>();
+	else if (younger >= 2) roll_wait_vm<2>();
+	else roll_wait_vm<0>();
+}
+
+/* 16 bytes of ring row `row` at a 16-byte aligned offset */
+template <int TAPS>
+__device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS> &st, int row, uint32_t off)
+{
+	return *reinterpret_cast<const u32x4 *>(st.ring + (row & st.KM) * RING_ROW + off);
+}
+
+/* 16 bytes of ring row `row` at a pixel (4-byte) aligned offset.  A ds_read_b128 from an address
+ * that is not 16-byte aligned returns the right data on gfx950 but takes ~65 LDS cycles instead
+ * of 4 (measured), so the access is left to the compiler as 4-byte aligned: two ds_read2_b32. */
+struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
+template <int TAPS>
+__device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS> &st, int row, int off)
+{
+	if (st.abl & 2)
+		return *reinterpret_cast<const u32x4 *>(st.ring + (row & st.KM) * RING_ROW + (off & ~15));
+	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + (row & st.KM) * RING_ROW + off);
+	return u32x4{ v.a, v.b, v.c, v.d };
+}
+
+/* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
+ * h[i] = sum_t wx[i][t] * px8[i + t] for my 4 output columns */
+template <int TAPS, int NW>
+__device__ __forceinline__ void roll_hrow(const RollState<TAPS> &st, const f32x2 (&wx)[4][5],
+                                          int rowR, int rowB, f32x2 (&h)[4])
+{
+	const u32x4 pr = roll_ring_win(st, rowR, st.tap[0]);
+	const u32x4 pb = roll_ring_win(st, rowB, st.tap[1]);
+	constexpr int NP = NW + 3;                      /* pixels of the 8 that carry weight */
+	f32x2 tp[NP];
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
+#pragma unroll
+	for (int k = 4; k < NP; ++k) {
+		const uint32_t nr = next_lane(pr[k - 4]), nb = next_lane(pb[k - 4]);
+		tp[k] = f32x2{ (float)(nr & 0xffu), (float)((nb >> 16) & 0xffu) };
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		f32x2 a = wx[i][0] * tp[i];
+#pragma unroll
+		for (int t = 1; t < NW; ++t) a = __builtin_elementwise_fma(wx[i][t], tp[i + t], a);
+		h[i] = a;
+	}
+}
+
+/* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
+template <int TAPS>
+__device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&acc)[4], const u32x4 &idt)
+{
+	u32x4 out;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].x, 0, idt[k]);
+		out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
+	}
+	if (st.abl & 8) {
+		if (st.active) __builtin_nontemporal_store(out, reinterpret_cast<u32x4 *>(st.gdst + st.so_st + st.vo_st));
+	} else
+		/* The row offset is added into the vector offset on purpose.  With the row offset in the
+		 * scalar-offset operand hipcc emits no wait state between a 16-byte buffer store and the
+		 * next write of its data registers (its hazard table exempts stores with an SGPR soffset);
+		 * on MI355X that store then picks up the NEXT row's bytes in the last quarter of each
+		 * 16-lane group (seen as sporadic wrong pixels).  With a constant soffset the compiler
+		 * handles the hazard. */
+		__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, 2 /* nt */);
+	st.so_st += st.pitch;
+	/* stores are NOT counted in seq: see the fetch function */
+}
+
+/* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
+ * window touches the top or bottom edge: edge rows replicate, fix-ca.c:1218-1256) */
+template <int TAPS, int NW>
+__device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&wx)[4][5], int r, int y)
+{
+	constexpr int T = TAPS;
+	const int j = r & 63;
+	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j));
+	const u32x4 idt = roll_ring_px(st, y, st.my_idt);
+	const int rbR = rrl(st.t_rb[0], j), rbB = rrl(st.t_rb[1], j);
+	f32x2 rows[T][4];
+#pragma unroll
+	for (int t = 0; t < T; ++t)
+		roll_hrow<TAPS, NW>(st, wx, rclampi(rbR + t, 0, st.H - 1), rclampi(rbB + t, 0, st.H - 1), rows[t]);
+	f32x2 v[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
+#pragma unroll
+	for (int t = 0; t < T; ++t) {
+		const f32x2 wy = { rrlf(st.t_wy[0][t], j), rrlf(st.t_wy[1][t], j) };
+#pragma unroll
+		for (int k = 0; k < 4; ++k) v[k] = __builtin_elementwise_fma(wy, rows[t][k], v[k]);
+	}
+#pragma unroll
+	for (int t = 0; t + 1 < T; ++t)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[t + 1][k];
+	roll_store(st, v, idt);
+}
+
+/* 4 consecutive output rows whose windows each slide down by one unclamped source row: all ring
+ * reads of the 4 rows are issued together, then 4 x (horizontal, vertical), then 4 stores */
+template <int TAPS, int NW>
+__device__ __forceinline__ void roll_block4(RollState<TAPS> &st, const f32x2 (&wx)[4][5], int r, int y)
+{
+	constexpr int T = TAPS;
+	const int j = r & 63;
+	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j + 3));
+	const int nR = rrl(st.t_rb[0], j) + T - 1, nB = rrl(st.t_rb[1], j) + T - 1;   /* newest row of output row r */
+
+	u32x4 idt[4];
+	f32x2 rows[T - 1 + 4][4];                       /* hist rows, then the 4 new rows */
+#pragma unroll
+	for (int t = 0; t + 1 < T; ++t)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rows[t][k] = st.hist[t][k];
+#pragma unroll
+	for (int n = 0; n < 4; ++n) {
+		idt[n] = roll_ring_px(st, y + n, st.my_idt);
+		roll_hrow<TAPS, NW>(st, wx, nR + n, nB + n, rows[T - 1 + n]);
+	}
+	f32x2 acc[4][4];
+#pragma unroll
+	for (int n = 0; n < 4; ++n) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) acc[n][k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
+#pragma unroll
+		for (int t = 0; t < T; ++t) {
+			const f32x2 wy = { rrlf(st.t_wy[0][t], j + n), rrlf(st.t_wy[1][t], j + n) };
+#pragma unroll
+			for (int k = 0; k < 4; ++k) acc[n][k] = __builtin_elementwise_fma(wy, rows[n + t][k], acc[n][k]);
+		}
+	}
+#pragma unroll
+	for (int t = 0; t + 1 < T; ++t)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[4 + t][k];
+#pragma unroll
+	for (int n = 0; n < 4; ++n) roll_store(st, acc[n], idt[n]);
+}
+
+template <int TAPS>          /* 2 = LINEAR, 4 = CUBIC */
+__global__ __launch_bounds__(64) void
+k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, FixcaPlan pl)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	constexpr int T = TAPS;
+	constexpr int BACK = (TAPS == 4) ? 1 : 0;
+
+	const int lane = threadIdx.x;
+	const int tile = xcd_remap(blockIdx.x, pl.nblocks);
+	if (tile >= pl.nwaves) return;
+	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
+	const int W = g.W, H = g.H, oc = pl.oc;
+	int X0 = strip * oc;
+	if (X0 > W - oc) X0 = W - oc;                   /* the last strip slides left: every strip is full */
+	const int Y0 = g.y1 + chunk * pl.th;
+	const int nrows = min(pl.th, g.y2 - Y0);
+
+	RollState<TAPS> st;
+	st.lane = lane;
+	st.abl = pl.ablate;
+	st.KM = pl.ring - 1;                            /* ring rows: power of two */
+	st.H = H;
+	st.pitch = (uint32_t)W * 4u;
+	st.gsrc = src; st.gdst = dst;
+	st.ring = lds + RING_PAD_LO;
+	{
+		/* descriptors are built from kernel arguments only, so they are provably wave-uniform */
+		const uint32_t total = (uint32_t)W * (uint32_t)H * 4u;      /* < 4 GB: the planner checks */
+		st.rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, total, 0x00020000);
+		st.rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total, 0x00020000);
+	}
+
+	/* ---- the 256-column source window of this strip (wave-uniform) ------------------- */
+	int lo = X0;
+#pragma unroll
+	for (int c = 0; c < 2; ++c)
+		lo = min(lo, rclampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1));
+	const int U0 = __builtin_amdgcn_readfirstlane(min(lo & ~3, W - FIXCA_WAVE_COLS));
+
+	/* ---- row mapping (shared by the row table and the bounds below) ------------------- */
+	auto row_of = [&](int y, int c, int &rb, float *wy) {
+		double yd = map_dbl(y, g.yc, H, g.s[c], g.ys[c]);
+		int y0 = (int)floor(yd);
+		if (wy) tap_weights<T>(yd - (double)y0, wy);
+		rb = y0 - BACK;
+	};
+	auto build_rows = [&](int rbase) {               /* lane j <- output row Y0 + rbase + j */
+		const int yr = min(Y0 + rbase + lane, H - 1);
+		int keep = yr, need = yr;
+		bool reg = (rbase + lane) > 0;
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			row_of(yr, c, st.t_rb[c], st.t_wy[c]);
+			int prev;
+			row_of(max(yr - 1, 0), c, prev, nullptr);
+			reg = reg && (st.t_rb[c] == prev + 1) && (st.t_rb[c] >= 0) && (st.t_rb[c] + T - 1 <= H - 1);
+			keep = min(keep, rclampi(st.t_rb[c], 0, H - 1));
+			need = max(need, rclampi(st.t_rb[c] + T - 1, 0, H - 1));
+		}
+		st.t_keep = keep;
+		st.t_need = need;
+		st.regmask = __ballot(reg);
+	};
+
+	/* the last source row this wave will ever need */
+	{
+		const int yl = Y0 + nrows - 1;
+		int ln = yl;
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			int rb;
+			row_of(yl, c, rb, nullptr);
+			ln = max(ln, rclampi(rb + T - 1, 0, H - 1));
+		}
+		st.lastneed = __builtin_amdgcn_readfirstlane(ln);
+	}
+
+	build_rows(0);
+	st.ld = rrl(st.t_keep, 0) - 1;
+	st.seq = 0;
+	st.seqtab = 0;
+	st.vo_ld = (uint32_t)(U0 + 4 * lane) * 4u;
+	st.so_ld = (uint32_t)(st.ld + 1) * st.pitch;
+	/* start filling the ring before the (fp64-heavy) lane constants are computed */
+	{
+		const int keep0 = rrl(st.t_keep, 0), need0 = rrl(st.t_need, 0);
+		const int target = min(min(need0 + RDEPTH, keep0 + st.KM), st.lastneed);
+		while (st.ld < target) roll_issue(st);
+	}
+
+	/* ---- per-lane column constants ------------------------------------------------ */
+	const int nact = oc >> 2;                        /* lanes that produce output */
+	st.active = lane < nact;
+	const int xl = X0 + 4 * min(lane, nact - 1);     /* first output column of this lane */
+
+	/* tap columns (clamped as the reference clamps them) and weights of my 4 outputs */
+	int   col[2][4][T];
+	float wt[2][4][T];
+	int   mlo[2] = { 1 << 30, 1 << 30 };             /* min over the strip of (tap column - x), taps with weight */
+#pragma unroll
+	for (int c = 0; c < 2; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int x = xl + i;
+			const double xd = map_dbl(x, g.xc, W, g.s[c], g.xs[c]);
+			const int x0 = (int)floor(xd);
+			tap_weights<T>(xd - (double)x0, wt[c][i]);
+			if constexpr (T == 4) {
+				col[c][i][0] = max(x0 - 1, 0);                      /* fix-ca.c:1270-1298 */
+				col[c][i][1] = x0;
+				col[c][i][2] = min(x0 + 1, W - 1);
+				col[c][i][3] = min(col[c][i][2] + 1, W - 1);
+			} else {
+				col[c][i][0] = x0;                                  /* fix-ca.c:1170-1177 */
+				col[c][i][1] = min(x0 + 1, W - 1);
+			}
+			/* a coordinate clamped to the image edge has fraction 0 and all its weight on one
+			 * column: taps with weight exactly 0 do not count (they may lie far off the others) */
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+				if (wt[c][i][t] != 0.f) mlo[c] = min(mlo[c], col[c][i][t] - x);
+		}
+	/* strip minimum: butterfly over the wave (inactive lanes carry copies of lane nact-1) */
+#pragma unroll
+	for (int c = 0; c < 2; ++c) {
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) mlo[c] = min(mlo[c], __shfl_xor(mlo[c], m, 64));
+		mlo[c] = __builtin_amdgcn_readfirstlane(mlo[c]);
+	}
+
+	/* fold steps and clamped taps into 5 weights per output: pixel i + j of my 8 has column
+	 * X0 + mlo + 4*lane + i + j, so tap t of output i lands on j = col - x - mlo, 0 <= j <= 4
+	 * for every tap with weight (the planner guarantees the range) */
+	f32x2 wx[4][5];
+	bool gen = false;
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int jj = 0; jj < 5; ++jj) {
+			float a[2] = { 0.f, 0.f };
+#pragma unroll
+			for (int c = 0; c < 2; ++c)
+#pragma unroll
+				for (int t = 0; t < T; ++t)
+					a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
+			wx[i][jj] = f32x2{ a[0], a[1] };
+			if (jj >= T) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
+		}
+	gen = __any(gen && st.active) != 0;
+
+#pragma unroll
+	for (int c = 0; c < 2; ++c)
+		st.tap[c] = (X0 + mlo[c] - U0 + 4 * lane) * 4;
+	st.my_idt = (uint32_t)((X0 - U0) * 4) + (uint32_t)min(lane, nact - 1) * 16;
+	/* a lane without output stores at offset `total`: past the end whether or not the range check
+	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
+	st.vo_st = st.active ? (uint32_t)xl * 4u : (uint32_t)W * (uint32_t)H * 4u;
+	st.so_st = (uint32_t)Y0 * st.pitch;
+
+	auto run = [&](auto nw_tag) {
+		constexpr int NW = decltype(nw_tag)::value;
+		int r = 0;
+		while (r < nrows) {
+			const int j = r & 63;
+			if (r && j == 0) build_rows(r);
+			if (j + 3 < 64 && r + 3 < nrows && ((st.regmask >> j) & 0xFull) == 0xFull) {
+				roll_block4<TAPS, NW>(st, wx, r, Y0 + r);
+				r += 4;
+			} else {
+				roll_row_any<TAPS, NW>(st, wx, r, Y0 + r);
+				r += 1;
+			}
+		}
+	};
+	if (gen) run(std::integral_constant<int, 5>{});
+	else     run(std::integral_constant<int, T>{});
+}
+
+extern "C" hipError_t
+fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+{
+	const uint8_t *s = static_cast<const uint8_t *>(d_src);
+	uint8_t *d = static_cast<uint8_t *>(d_dst);
+	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void *)k_roll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		attr_done = true;
+	}
+	if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
+	else                hipLaunchKernelGGL(k_roll<4>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
+	return hipGetLastError();
+}

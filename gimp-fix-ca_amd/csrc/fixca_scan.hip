@@ -92,7 +92,7 @@ struct ScanState {
 	int      KM, H;
 	int      ld;                /* highest source row issued                                   */
 	int      lastneed;          /* highest source row this wave ever needs                     */
-	int      seq, seqtab;       /* vector-memory ops issued; lane s: seq of the load in slot s */
+	int      seq, seqtab;       /* loads issued; lane s: seq of the load in slot s              */
 	const uint8_t *gld;         /* global address of my 16 bytes of source row ld + 1          */
 	uint8_t *gout;              /* global address of my 16 bytes of the next output row        */
 	size_t   pitch;
@@ -113,15 +113,23 @@ __device__ __forceinline__ void scan_issue(ScanState<TAPS> &st)
 }
 
 /* keep DEPTH rows in flight beyond `need` (within the ring's capacity), then wait until row
- * `need` has landed; operations issued after its load may stay outstanding */
+ * `need` has landed.
+ * vmcnt counts loads and stores together, and on gfx9-family hardware loads complete in order
+ * among loads and stores among stores, but NOT across the two kinds (a young store may be
+ * acknowledged before an old load has landed; seen on MI355X as partially landed ring rows).
+ * So the wait may only rely on loads: with L loads younger than the one needed, "at most L
+ * operations outstanding" implies "at most L loads outstanding", which implies the needed
+ * load is done.  seq therefore counts loads only, and stores in flight merely make the wait
+ * stricter, never wrong. */
 template <int TAPS>
 __device__ __forceinline__ void scan_fetch(ScanState<TAPS> &st, int keep, int need)
 {
 	const int target = min(min(need + DEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) scan_issue(st);
 	const int younger = st.seq - rl(st.seqtab, need & st.KM) - 1;
-	if (younger >= 2 * DEPTH) wait_vm<2 * DEPTH>();
-	else if (younger >= DEPTH) wait_vm<DEPTH>();
+	if (younger >= 6) wait_vm<6>();
+	else if (younger >= 4) wait_vm<4>();
+	else if (younger >= 2) wait_vm<2>();
 	else wait_vm<0>();
 }
 
@@ -209,7 +217,7 @@ __device__ __forceinline__ void scan_store(ScanState<TAPS> &st, const f32x2 acc[
 	if (st.active)
 		__builtin_nontemporal_store(out, reinterpret_cast<u32x4 *>(st.gout));
 	st.gout += st.pitch;
-	++st.seq;                                        /* the store is one vector-memory operation */
+	/* stores are NOT counted in seq: see the fetch function */
 }
 
 /* NONE: NR output rows, each a byte gather out of the ring */
@@ -242,7 +250,6 @@ __device__ __forceinline__ void scan_rows_none(ScanState<0> &st, int r, int y)
 		if (st.active)
 			__builtin_nontemporal_store(out, reinterpret_cast<u32x4 *>(st.gout));
 		st.gout += st.pitch;
-		++st.seq;
 	}
 }
 
@@ -817,7 +824,6 @@ k_scanw(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g,
 			}
 			if (st.active)
 				__builtin_nontemporal_store(out, reinterpret_cast<u32x4 *>(st.gout));
-			++st.seq;
 		}
 		st.gout += ostep;
 	}

@@ -280,14 +280,17 @@ def test_cli_end_to_end(torch_cuda, tmp_path):
 # ---- every fast kernel variant on the same inputs ------------------------------------------------
 
 VARIANTS = {
-    "scan": {},                                   # LDS-ring scan, one wave per strip (default for RGBA, W % 4 == 0)
-    "scan-th7": {"FIXCA_TH": "7"},                # short chunks: generic rows dominate, odd tails
-    "scan-th200": {"FIXCA_TH": "200"},            # chunks longer than one 64-row table
-    "scanw": {"FIXCA_SCANW": "1"},                # ring shared by the 4 waves of a workgroup
-    "scanw-th13": {"FIXCA_SCANW": "1", "FIXCA_TH": "13"},
-    "regwin": {"FIXCA_NO_SCAN": "1"},             # register-window kernels
+    "roll": {},                                   # LDS ring + horizontal-first rolling window (default for RGBA, W % 4 == 0)
+    "roll-th7": {"FIXCA_TH": "7"},                # short chunks: generic rows dominate, odd tails
+    "roll-th200": {"FIXCA_TH": "200"},            # chunks longer than one 64-row table
+    "scan": {"FIXCA_NO_ROLL": "1"},               # LDS-ring scan with the exchange array, one wave per strip
+    "scan-th7": {"FIXCA_NO_ROLL": "1", "FIXCA_TH": "7"},
+    "scan-th200": {"FIXCA_NO_ROLL": "1", "FIXCA_TH": "200"},
+    "scanw": {"FIXCA_NO_ROLL": "1", "FIXCA_SCANW": "1"},   # ring shared by the 4 waves of a workgroup
+    "scanw-th13": {"FIXCA_NO_ROLL": "1", "FIXCA_SCANW": "1", "FIXCA_TH": "13"},
+    "regwin": {"FIXCA_NO_ROLL": "1", "FIXCA_NO_SCAN": "1"},   # register-window kernels
 }
-SCAN_SHAPES = [(256, 70), (260, 33), (512, 300), (1000, 50), (1024, 257)]
+SCAN_SHAPES = [(256, 70), (260, 33), (512, 300), (1000, 50), (1024, 257), (2048, 72)]
 SCAN_PARAMS = [
     dict(blue=2.0, red=-2.0, lens_x=0.1, lens_y=0.3),
     dict(blue=-3.3, red=4.7, lens_x=-1, lens_y=-1, x_blue=2.5, x_red=-1.25, y_blue=.75, y_red=-3),
@@ -307,7 +310,11 @@ def test_kernel_variants_agree_with_oracle(torch_cuda, monkeypatch, variant, sha
     for interp in (0, 1, 2):
         p = fixca.make_params(interpolation=interp, **_scaled(SCAN_PARAMS[pi], w, h))
         kid, desc = fixca.plan(w, h, 4, 1, p, kernel=fixca.KERNEL_FAST)
-        if variant.startswith("scanw"):
+        if variant.startswith("roll"):
+            assert kid in (3, 4, 6), desc
+            if interp and pi in (0, 2) and w >= 2048:
+                assert kid == 6, desc                       # mild scales: the rolling kernel must take these
+        elif variant.startswith("scanw"):
             assert kid in (3, 5), desc
         elif variant.startswith("scan"):
             assert kid in (3, 4), desc

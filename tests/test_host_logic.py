@@ -33,6 +33,7 @@ def _params(kw, w, h, interp):
 @pytest.mark.parametrize("interp", [1, 2])
 def test_model_within_one_lsb(size, pset, interp, monkeypatch):
     monkeypatch.setenv("FIXCA_NO_SCAN", "1")       # the model describes the register-window kernel
+    monkeypatch.setenv("FIXCA_NO_ROLL", "1")
     w, h, c = size
     kw = _params(PSETS[pset], w, h, interp)
     p = fixca.make_params(interpolation=interp, **kw)
