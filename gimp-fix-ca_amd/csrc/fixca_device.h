@@ -106,4 +106,22 @@ __device__ __forceinline__ void tap_weights(double t, float w[TAPS])
 	}
 }
 
+/* The same tap weights evaluated in fp32 from the (exactly computed) fp64 fraction: used where
+ * many weights are needed per wave and 1e-7 relative error is far inside the 1-LSB budget.
+ * A fraction of exactly 0 gives exactly (0,1,0,0) / (1,0). */
+template <int TAPS>
+__device__ __forceinline__ void tap_weights_f32(float t, float w[TAPS])
+{
+	if (TAPS == 4) {
+		float t2 = t * t, t3 = t2 * t;
+		w[0] = (-t3 + 2.0f * t2 - t) * 0.5f;
+		w[1] = (3.0f * t3 - 5.0f * t2 + 2.0f) * 0.5f;
+		w[2] = (-3.0f * t3 + 4.0f * t2 + t) * 0.5f;
+		w[3] = (t3 - t2) * 0.5f;
+	} else {
+		w[0] = 1.0f - t;
+		w[1] = t;
+	}
+}
+
 #endif

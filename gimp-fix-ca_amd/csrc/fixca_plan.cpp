@@ -229,49 +229,27 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 
 /* ---- plan for the row-rolling kernel (fixca_roll.hip) ----------------------------- */
 
-/* tap weights exactly as the kernels compute them (fixca_device.h tap_weights: fp64 polynomial,
- * rounded to fp32); only "is it zero" matters here */
-static void h_tap_weights(double t, int taps, float *w)
-{
-	if (taps == 4) {
-		double t2 = t * t, t3 = t2 * t;
-		w[0] = (float)((-t3 + 2.0 * t2 - t) * 0.5);
-		w[1] = (float)((3.0 * t3 - 5.0 * t2 + 2.0) * 0.5);
-		w[2] = (float)((-3.0 * t3 + 4.0 * t2 + t) * 0.5);
-		w[3] = (float)((t3 - t2) * 0.5);
-	} else {
-		w[0] = (float)(1.0 - t);
-		w[1] = (float)t;
-	}
-}
-
 /* first and last tap column WITH WEIGHT of output column x, clamped as the reference clamps
- * them (fix-ca.c:1170-1177 linear, :1270-1298 cubic).  A coordinate clamped to the image edge
- * has fraction 0 and all its weight on one column. */
+ * them (fix-ca.c:1170-1177 linear, :1270-1298 cubic).  A coordinate exactly on a column (every
+ * coordinate clamped to the image edge is) has all its weight on that column; k_roll takes the
+ * same decision on the same fp64 fraction. */
 static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int *last)
 {
 	const int W = g->W;
 	const double xd = h_map_dbl(x, g->xc, W, g->s[c], g->xs[c]);
 	const int x0 = (int)floor(xd);
-	int col[4];
-	float w[4];
-	h_tap_weights(xd - (double)x0, taps, w);
-	if (taps == 4) {
-		col[0] = x0 - 1 > 0 ? x0 - 1 : 0;
-		col[1] = x0;
-		col[2] = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
-		col[3] = col[2] + 1 < W - 1 ? col[2] + 1 : W - 1;
-	} else {
-		col[0] = x0;
-		col[1] = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
+	if (xd - (double)x0 == 0.0) {
+		*first = *last = x0;
+		return;
 	}
-	*first = INT_MAX;
-	*last = INT_MIN;
-	for (int t = 0; t < taps; ++t)
-		if (w[t] != 0.f) {
-			if (col[t] < *first) *first = col[t];
-			if (col[t] > *last) *last = col[t];
-		}
+	if (taps == 4) {
+		int c2 = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
+		*first = x0 - 1 > 0 ? x0 - 1 : 0;
+		*last = c2 + 1 < W - 1 ? c2 + 1 : W - 1;
+	} else {
+		*first = x0;
+		*last = x0 + 1 < W - 1 ? x0 + 1 : W - 1;
+	}
 }
 
 /* Every strip must satisfy what k_roll assumes: with m = min over the strip of (tap column - x),
@@ -333,14 +311,27 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 		pl->oc = oc;
 		pl->ring = ring;
 		pl->nstrips = (g->W + oc - 1) / oc;
-		/* one round of waves: as many rows per wave as it takes for every wave to be resident
-		 * at once (LDS: ring + pads per wave; 160 KB per CU, 256 CUs) */
-		const int per_cu = (160 * 1024) / (ring * 1024 + 512);
-		int max_chunks = per_cu * 256 / pl->nstrips;
-		if (max_chunks < 1) max_chunks = 1;
-		int th = (rows + max_chunks - 1) / max_chunks;
-		if (th < 16) th = 16;
-		pl->th = env_int("FIXCA_TH", th, 1, 1 << 20);
+		/* Rows per wave.  Every wave should be resident at once (one round): a CU holds
+		 * `per_cu` waves (LDS: ring + pads per wave, 160 KB per CU; registers: the cubic kernel
+		 * runs 2 waves per SIMD), and the waves of a launch spread evenly over the 256 CUs.  A
+		 * wave's time is (th + c) row times, c ~ 12 rows being its fixed cost (lane constants,
+		 * first window); a row time grows with the k = ceil(waves / 256) waves sharing a CU about
+		 * as 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9): mostly latency, partly
+		 * throughput.  th = 4m + 1: the first row of a wave rebuilds its window, the rest go 4
+		 * at a time. */
+		int per_cu = (160 * 1024) / (ring * 1024 + 512);
+		if (per_cu > 8) per_cu = 8;
+		int best_th = 0;
+		long best_cost = 0;
+		for (int th = 17; th <= 1025; th += 4) {
+			const long chunks = (rows + th - 1) / th;
+			const long per = (chunks * pl->nstrips + 255) / 256;
+			if (per > per_cu && th < 1025) continue;
+			const long cost = (27 + 5 * per) * (th + 12);
+			if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
+			if (chunks == 1) break;
+		}
+		pl->th = env_int("FIXCA_TH", best_th, 1, 1 << 20);
 		pl->nchunks = (rows + pl->th - 1) / pl->th;
 		if (pl->nchunks < 1) pl->nchunks = 1;
 		pl->nwaves = pl->nstrips * pl->nchunks;

@@ -67,14 +67,13 @@ __device__ __forceinline__ float rrlf(float v, int lane)
 /* the dword lane L + 1 holds (0 in lane 63): DPP wave_shl:1 */
 __device__ __forceinline__ uint32_t next_lane(uint32_t v)
 {
-	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+	return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);
 }
 
 template <int TAPS>
 struct RollState {
 	static constexpr int T = TAPS;
 	int      lane;
-	int      abl;               /* timing experiments (FIXCA_ABLATE): 1 no DPP, 2 aligned window reads, 4 no vertical weights broadcast */
 	bool     active;
 	int      tap[2];            /* byte offset (may be negative) of my 4-pixel window in a ring row */
 	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
@@ -97,7 +96,6 @@ struct RollState {
 	uint32_t so_ld;             /* byte offset of source row ld + 1                             */
 	uint32_t so_st;             /* byte offset of the next output row                           */
 	uint32_t pitch;
-	const uint8_t *gsrc; uint8_t *gdst;   /* experiments: flat-address forms of the same accesses */
 	/* the newest T-1 horizontally filtered rows, (red, blue) of my 4 output columns */
 	f32x2    hist[T - 1][4];
 };
@@ -107,10 +105,6 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS> &st)
 {
 	++st.ld;
 	const int slot = st.ld & st.KM;
-	if (st.abl & 4)
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st.gsrc + st.so_ld + st.vo_ld),
-		                                 (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW), 16, 0, 0);
-	else
 #if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW),
 	                                         16, st.vo_ld, st.so_ld, 0, 0);
@@ -135,8 +129,7 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS> &st, int keep, int ne
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) roll_issue(st);
 	const int younger = st.seq - rrl(st.seqtab, need & st.KM) - 1;
-	if (st.abl & 1) roll_wait_vm<0>();
-	else if (younger >= 6) roll_wait_vm<6>();
+	if (younger >= 6) roll_wait_vm<6>();
 	else if (younger >= 4) roll_wait_vm<4>();
 	else if (younger >= 2) roll_wait_vm<2>();
 	else roll_wait_vm<0>();
@@ -156,8 +149,6 @@ struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
 template <int TAPS>
 __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS> &st, int row, int off)
 {
-	if (st.abl & 2)
-		return *reinterpret_cast<const u32x4 *>(st.ring + (row & st.KM) * RING_ROW + (off & ~15));
 	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + (row & st.KM) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, v.d };
 }
@@ -199,16 +190,13 @@ __device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&ac
 		uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].x, 0, idt[k]);
 		out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
 	}
-	if (st.abl & 8) {
-		if (st.active) __builtin_nontemporal_store(out, reinterpret_cast<u32x4 *>(st.gdst + st.so_st + st.vo_st));
-	} else
-		/* The row offset is added into the vector offset on purpose.  With the row offset in the
-		 * scalar-offset operand hipcc emits no wait state between a 16-byte buffer store and the
-		 * next write of its data registers (its hazard table exempts stores with an SGPR soffset);
-		 * on MI355X that store then picks up the NEXT row's bytes in the last quarter of each
-		 * 16-lane group (seen as sporadic wrong pixels).  With a constant soffset the compiler
-		 * handles the hazard. */
-		__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, 2 /* nt */);
+	/* The row offset is added into the vector offset on purpose.  With the row offset in the
+	 * scalar-offset operand hipcc emits no wait state between a 16-byte buffer store and the
+	 * next write of its data registers (its hazard table exempts stores with an SGPR soffset);
+	 * on MI355X that store then picks up the NEXT row's bytes in the last quarter of each
+	 * 16-lane group (seen as sporadic wrong pixels).  With a constant soffset the compiler
+	 * handles the hazard. */
+	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, 2 /* nt */);
 	st.so_st += st.pitch;
 	/* stores are NOT counted in seq: see the fetch function */
 }
@@ -243,45 +231,72 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&
 	roll_store(st, v, idt);
 }
 
-/* 4 consecutive output rows whose windows each slide down by one unclamped source row: all ring
- * reads of the 4 rows are issued together, then 4 x (horizontal, vertical), then 4 stores */
-template <int TAPS, int NW>
-__device__ __forceinline__ void roll_block4(RollState<TAPS> &st, const f32x2 (&wx)[4][5], int r, int y)
+/* NR (1..4) consecutive output rows whose windows each slide down by one unclamped source row.
+ * All ring reads of the rows are issued together; the filter arithmetic is written tap-major
+ * (for each tap, all rows and outputs) so that consecutive instructions belong to different
+ * accumulation chains: a wave shares its SIMD with one or two others at most and has to cover
+ * its own FMA latency. */
+template <int TAPS, int NW, int NR>
+__device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx)[4][5], int r, int y)
 {
 	constexpr int T = TAPS;
+	constexpr int NP = NW + 3;                      /* pixels of the 8 that carry weight */
 	const int j = r & 63;
-	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j + 3));
+	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j + NR - 1));
 	const int nR = rrl(st.t_rb[0], j) + T - 1, nB = rrl(st.t_rb[1], j) + T - 1;   /* newest row of output row r */
 
-	u32x4 idt[4];
-	f32x2 rows[T - 1 + 4][4];                       /* hist rows, then the 4 new rows */
+	u32x4 idt[NR], pr[NR], pb[NR];
+#pragma unroll
+	for (int n = 0; n < NR; ++n) {
+		pr[n] = roll_ring_win(st, nR + n, st.tap[0]);
+		pb[n] = roll_ring_win(st, nB + n, st.tap[1]);
+		idt[n] = roll_ring_px(st, y + n, st.my_idt);
+	}
+	f32x2 rows[T - 1 + NR][4];                      /* hist rows, then the NR new rows */
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rows[t][k] = st.hist[t][k];
+
+	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
+	f32x2 tp[NR][NP];
 #pragma unroll
-	for (int n = 0; n < 4; ++n) {
-		idt[n] = roll_ring_px(st, y + n, st.my_idt);
-		roll_hrow<TAPS, NW>(st, wx, nR + n, nB + n, rows[T - 1 + n]);
-	}
-	f32x2 acc[4][4];
+	for (int n = 0; n < NR; ++n) {
 #pragma unroll
-	for (int n = 0; n < 4; ++n) {
+		for (int k = 0; k < 4; ++k)
+			tp[n][k] = f32x2{ (float)(pr[n][k] & 0xffu), (float)((pb[n][k] >> 16) & 0xffu) };
 #pragma unroll
-		for (int k = 0; k < 4; ++k) acc[n][k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
-#pragma unroll
-		for (int t = 0; t < T; ++t) {
-			const f32x2 wy = { rrlf(st.t_wy[0][t], j + n), rrlf(st.t_wy[1][t], j + n) };
-#pragma unroll
-			for (int k = 0; k < 4; ++k) acc[n][k] = __builtin_elementwise_fma(wy, rows[n + t][k], acc[n][k]);
+		for (int k = 4; k < NP; ++k) {
+			const uint32_t nr = next_lane(pr[n][k - 4]), nb = next_lane(pb[n][k - 4]);
+			tp[n][k] = f32x2{ (float)(nr & 0xffu), (float)((nb >> 16) & 0xffu) };
 		}
 	}
 #pragma unroll
+	for (int t = 0; t < NW; ++t)
+#pragma unroll
+		for (int n = 0; n < NR; ++n)
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				rows[T - 1 + n][i] = (t == 0) ? wx[i][0] * tp[n][i]
+				                              : __builtin_elementwise_fma(wx[i][t], tp[n][i + t], rows[T - 1 + n][i]);
+
+	/* vertical: acc[n][k] = bias + sum_t wy[n][t] * rows[n + t][k] */
+	f32x2 acc[NR][4];
+#pragma unroll
+	for (int t = 0; t < T; ++t)
+#pragma unroll
+		for (int n = 0; n < NR; ++n) {
+			const f32x2 wy = { rrlf(st.t_wy[0][t], j + n), rrlf(st.t_wy[1][t], j + n) };
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				acc[n][k] = __builtin_elementwise_fma(wy, rows[n + t][k], (t == 0) ? f32x2{ ROUND_BIAS, ROUND_BIAS } : acc[n][k]);
+		}
+#pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
-		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[4 + t][k];
+		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[NR + t][k];
 #pragma unroll
-	for (int n = 0; n < 4; ++n) roll_store(st, acc[n], idt[n]);
+	for (int n = 0; n < NR; ++n) roll_store(st, acc[n], idt[n]);
 }
 
 template <int TAPS>          /* 2 = LINEAR, 4 = CUBIC */
@@ -304,11 +319,9 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 
 	RollState<TAPS> st;
 	st.lane = lane;
-	st.abl = pl.ablate;
 	st.KM = pl.ring - 1;                            /* ring rows: power of two */
 	st.H = H;
 	st.pitch = (uint32_t)W * 4u;
-	st.gsrc = src; st.gdst = dst;
 	st.ring = lds + RING_PAD_LO;
 	{
 		/* descriptors are built from kernel arguments only, so they are provably wave-uniform */
@@ -328,7 +341,7 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	auto row_of = [&](int y, int c, int &rb, float *wy) {
 		double yd = map_dbl(y, g.yc, H, g.s[c], g.ys[c]);
 		int y0 = (int)floor(yd);
-		if (wy) tap_weights<T>(yd - (double)y0, wy);
+		if (wy) tap_weights_f32<T>((float)(yd - (double)y0), wy);
 		rb = y0 - BACK;
 	};
 	auto build_rows = [&](int rbase) {               /* lane j <- output row Y0 + rbase + j */
@@ -383,6 +396,8 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	/* tap columns (clamped as the reference clamps them) and weights of my 4 outputs */
 	int   col[2][4][T];
 	float wt[2][4][T];
+	bool  whole[2][4];                               /* fraction != 0: all T taps carry weight */
+	bool  plain = true;                              /* every output: whole, and T consecutive unclamped columns */
 	int   mlo[2] = { 1 << 30, 1 << 30 };             /* min over the strip of (tap column - x), taps with weight */
 #pragma unroll
 	for (int c = 0; c < 2; ++c)
@@ -391,7 +406,8 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 			const int x = xl + i;
 			const double xd = map_dbl(x, g.xc, W, g.s[c], g.xs[c]);
 			const int x0 = (int)floor(xd);
-			tap_weights<T>(xd - (double)x0, wt[c][i]);
+			const double fx = xd - (double)x0;
+			tap_weights_f32<T>((float)fx, wt[c][i]);
 			if constexpr (T == 4) {
 				col[c][i][0] = max(x0 - 1, 0);                      /* fix-ca.c:1270-1298 */
 				col[c][i][1] = x0;
@@ -401,11 +417,20 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 				col[c][i][0] = x0;                                  /* fix-ca.c:1170-1177 */
 				col[c][i][1] = min(x0 + 1, W - 1);
 			}
-			/* a coordinate clamped to the image edge has fraction 0 and all its weight on one
-			 * column: taps with weight exactly 0 do not count (they may lie far off the others) */
+			/* A coordinate that sits exactly on a column (every coordinate clamped to the image
+			 * edge does) has all its weight on that column; its other taps, which may lie far
+			 * from the rest of the strip's, do not count.  Host and device take this decision on
+			 * the fp64 fraction, where they agree bit for bit. */
+			whole[c][i] = (fx != 0.0);
+			constexpr int CT = (T == 4) ? 1 : 0;                    /* the tap with weight 1 at fraction 0 */
+			if (whole[c][i]) {
+				mlo[c] = min(mlo[c], col[c][i][0] - x);
+			} else {
+				mlo[c] = min(mlo[c], col[c][i][CT] - x);
 #pragma unroll
-			for (int t = 0; t < T; ++t)
-				if (wt[c][i][t] != 0.f) mlo[c] = min(mlo[c], col[c][i][t] - x);
+				for (int t = 0; t < T; ++t) wt[c][i][t] = (t == CT) ? 1.0f : 0.0f;
+			}
+			plain = plain && whole[c][i] && (col[c][i][T - 1] - col[c][i][0] == T - 1);
 		}
 	/* strip minimum: butterfly over the wave (inactive lanes carry copies of lane nact-1) */
 #pragma unroll
@@ -420,19 +445,39 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	 * for every tap with weight (the planner guarantees the range) */
 	f32x2 wx[4][5];
 	bool gen = false;
+	if (__all(plain)) {
+		/* the usual strip: output i's taps are pixels i+k .. i+k+T-1 with k = 0 or a step */
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
+		for (int i = 0; i < 4; ++i) {
+			const int kR = col[0][i][0] - (xl + i) - mlo[0], kB = col[1][i][0] - (xl + i) - mlo[1];
+			gen = gen || kR != 0 || kB != 0;
 #pragma unroll
-		for (int jj = 0; jj < 5; ++jj) {
-			float a[2] = { 0.f, 0.f };
-#pragma unroll
-			for (int c = 0; c < 2; ++c)
+			for (int jj = 0; jj < 5; ++jj) {
+				float a0 = 0.f, a1 = 0.f;
 #pragma unroll
 				for (int t = 0; t < T; ++t)
-					a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
-			wx[i][jj] = f32x2{ a[0], a[1] };
-			if (jj >= T) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
+					if (jj - t >= 0 && jj - t <= 5 - T) {
+						a0 = (kR == jj - t) ? wt[0][i][t] : a0;
+						a1 = (kB == jj - t) ? wt[1][i][t] : a1;
+					}
+				wx[i][jj] = f32x2{ a0, a1 };
+			}
 		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int jj = 0; jj < 5; ++jj) {
+				float a[2] = { 0.f, 0.f };
+#pragma unroll
+				for (int c = 0; c < 2; ++c)
+#pragma unroll
+					for (int t = 0; t < T; ++t)
+						a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
+				wx[i][jj] = f32x2{ a[0], a[1] };
+				if (jj >= T) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
+			}
+	}
 	gen = __any(gen && st.active) != 0;
 
 #pragma unroll
@@ -451,8 +496,11 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 			const int j = r & 63;
 			if (r && j == 0) build_rows(r);
 			if (j + 3 < 64 && r + 3 < nrows && ((st.regmask >> j) & 0xFull) == 0xFull) {
-				roll_block4<TAPS, NW>(st, wx, r, Y0 + r);
+				roll_block<TAPS, NW, 4>(st, wx, r, Y0 + r);
 				r += 4;
+			} else if ((st.regmask >> j) & 1ull) {       /* tails and rows next to an irregular one */
+				roll_block<TAPS, NW, 1>(st, wx, r, Y0 + r);
+				r += 1;
 			} else {
 				roll_row_any<TAPS, NW>(st, wx, r, Y0 + r);
 				r += 1;
