@@ -317,16 +317,15 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 		 * wave's time is (th + c) row times, c ~ 12 rows being its fixed cost (lane constants,
 		 * first window); a row time grows with the k = ceil(waves / 256) waves sharing a CU about
 		 * as 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9): mostly latency, partly
-		 * throughput.  th = 4m + 1: the first row of a wave rebuilds its window, the rest go 4
-		 * at a time. */
-		int per_cu = (160 * 1024) / (ring * 1024 + 512);
+		 * throughput. */
+		int per_cu = (160 * 1024) / (ring * 1024 + 2560);   /* ring + pads + the 2 KB weight table */
 		if (per_cu > 8) per_cu = 8;
 		int best_th = 0;
 		long best_cost = 0;
-		for (int th = 17; th <= 1025; th += 4) {
+		for (int th = 16; th <= 1024; ++th) {
 			const long chunks = (rows + th - 1) / th;
 			const long per = (chunks * pl->nstrips + 255) / 256;
-			if (per > per_cu && th < 1025) continue;
+			if (per > per_cu && th < 1024) continue;
 			const long cost = (27 + 5 * per) * (th + 12);
 			if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
 			if (chunks == 1) break;

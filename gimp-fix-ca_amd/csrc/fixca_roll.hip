@@ -64,14 +64,37 @@ __device__ __forceinline__ float rrlf(float v, int lane)
 	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-/* the dword lane L + 1 holds (0 in lane 63): DPP wave_shl:1 */
-__device__ __forceinline__ uint32_t next_lane(uint32_t v)
+/* byte 0 / byte 2 of the dword lane L + 1 holds, as a float (0 in lane 63): the byte->float
+ * conversion with a DPP wave shift as its operand modifier.  Written as asm because hipcc folds
+ * the shift into the conversion only in some schedules and otherwise spends two extra moves per
+ * pixel.  No DPP hazard arises: the source registers are written by LDS loads, not by VALU. */
+__device__ __forceinline__ float next_lane_ubyte0(uint32_t v)
 {
-	return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);
+	float f;
+	asm("v_cvt_f32_ubyte0_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f) : "v"(v));
+	return f;
 }
+__device__ __forceinline__ float next_lane_ubyte2(uint32_t v)
+{
+	float f;
+	asm("v_cvt_f32_ubyte2_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f) : "v"(v));
+	return f;
+}
+
+/* FIXCA_EXP_STAMPS (timing experiment only, output image is overwritten with the numbers):
+ * s_memtime at the seams of a 4-row block, accumulated per wave */
+#if defined(FIXCA_EXP_STAMPS)
+#define STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st.acc[i] += t_ - st.last; st.last = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 template <int TAPS>
 struct RollState {
+#if defined(FIXCA_EXP_STAMPS)
+	unsigned long long last, acc[8];
+#endif
 	static constexpr int T = TAPS;
 	int      lane;
 	bool     active;
@@ -79,14 +102,14 @@ struct RollState {
 	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
 	/* row table: lane j describes output row Y0 + 64*blk + j */
 	int      t_rb[2], t_keep, t_need;
-	float    t_wy[2][T];
+	uint8_t *wtab;              /* LDS: vertical weights of the 64 rows of the table, row j at 32*j:
+	                               (red, blue) of tap 0, tap 1, ... as f32x2; v_readlane costs 3x a VALU op */
 	unsigned long long regmask; /* bit j: both windows of row j slide down by exactly one unclamped row */
 	/* ring */
 	uint8_t *ring;
 	int      KM, H;
 	int      ld;                /* highest source row issued                                   */
 	int      lastneed;          /* highest source row this wave ever needs                     */
-	int      seq, seqtab;       /* loads issued; lane s: seq of the load in slot s              */
 	/* global memory goes through buffer descriptors: the per-lane part of an address is a
 	 * constant 32-bit offset, the row part a scalar, and a lane that must not store gets an
 	 * offset outside the buffer (dropped by the range check) instead of a branch */
@@ -110,25 +133,26 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS> &st)
 	                                         16, st.vo_ld, st.so_ld, 0, 0);
 #endif
 	st.so_ld += st.pitch;
-	st.seqtab = (st.lane == slot) ? st.seq : st.seqtab;     /* v_writelane by hand */
-	++st.seq;
 }
 
 /* keep RDEPTH rows in flight beyond `need` (within the ring's capacity), then wait until row
  * `need` has landed.
- * vmcnt counts loads and stores together, and on gfx9-family hardware loads complete in order
- * among loads and stores among stores, but NOT across the two kinds (a young store may be
- * acknowledged before an old load has landed; seen on MI355X as partially landed ring rows).
- * So the wait may only rely on loads: with L loads younger than the one needed, "at most L
- * operations outstanding" implies "at most L loads outstanding", which implies the needed
- * load is done.  seq therefore counts loads only, and stores in flight merely make the wait
- * stricter, never wrong. */
+ * vmcnt counts loads and stores together.  Loads complete in order among loads and stores among
+ * stores, but the compiler's own model of gfx9-family hardware does not order a load against a
+ * store (a young store may be acknowledged before an old load has landed), so the wait relies
+ * on loads only: rows are loaded in order, one load each, so exactly ld - need loads are
+ * younger than the one needed, and "at most ld - need operations outstanding" implies "at most
+ * ld - need loads outstanding", which implies the needed row is in LDS.  Stores in flight make
+ * the wait stricter, never wrong. */
 template <int TAPS>
 __device__ __forceinline__ void roll_fetch(RollState<TAPS> &st, int keep, int need)
 {
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) roll_issue(st);
-	const int younger = st.seq - rrl(st.seqtab, need & st.KM) - 1;
+#if defined(FIXCA_EXP_NOVMWAIT)                 /* timing experiment only: reads rows that may not have landed */
+	return;
+#endif
+	const int younger = st.ld - need;
 	if (younger >= 6) roll_wait_vm<6>();
 	else if (younger >= 4) roll_wait_vm<4>();
 	else if (younger >= 2) roll_wait_vm<2>();
@@ -149,8 +173,12 @@ struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
 template <int TAPS>
 __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS> &st, int row, int off)
 {
+#if defined(FIXCA_EXP_ALIGNED)                  /* timing experiment only: wrong pixels */
+	return *reinterpret_cast<const u32x4 *>(st.ring + (row & st.KM) * RING_ROW + (off & ~15));
+#else
 	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + (row & st.KM) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, v.d };
+#endif
 }
 
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
@@ -168,8 +196,7 @@ __device__ __forceinline__ void roll_hrow(const RollState<TAPS> &st, const f32x2
 		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
 #pragma unroll
 	for (int k = 4; k < NP; ++k) {
-		const uint32_t nr = next_lane(pr[k - 4]), nb = next_lane(pb[k - 4]);
-		tp[k] = f32x2{ (float)(nr & 0xffu), (float)((nb >> 16) & 0xffu) };
+		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
 	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
@@ -177,6 +204,20 @@ __device__ __forceinline__ void roll_hrow(const RollState<TAPS> &st, const f32x2
 #pragma unroll
 		for (int t = 1; t < NW; ++t) a = __builtin_elementwise_fma(wx[i][t], tp[i + t], a);
 		h[i] = a;
+	}
+}
+
+/* the T (red, blue) vertical weight pairs of table row j: a broadcast LDS read */
+template <int TAPS>
+__device__ __forceinline__ void roll_wy(const RollState<TAPS> &st, int j, f32x2 (&wy)[TAPS])
+{
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+	const f32x4 *p = reinterpret_cast<const f32x4 *>(st.wtab + j * 32);
+#pragma unroll
+	for (int h = 0; h < TAPS / 2; ++h) {
+		const f32x4 q = p[h];
+		wy[2 * h] = f32x2{ q.x, q.y };
+		wy[2 * h + 1] = f32x2{ q.z, q.w };
 	}
 }
 
@@ -198,7 +239,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&ac
 	 * handles the hazard. */
 	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, 2 /* nt */);
 	st.so_st += st.pitch;
-	/* stores are NOT counted in seq: see the fetch function */
+	/* stores are not counted by the fetch function's wait: see there */
 }
 
 /* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
@@ -218,12 +259,12 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&
 	f32x2 v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
+	f32x2 wy[T];
+	roll_wy<TAPS>(st, j, wy);
 #pragma unroll
-	for (int t = 0; t < T; ++t) {
-		const f32x2 wy = { rrlf(st.t_wy[0][t], j), rrlf(st.t_wy[1][t], j) };
+	for (int t = 0; t < T; ++t)
 #pragma unroll
-		for (int k = 0; k < 4; ++k) v[k] = __builtin_elementwise_fma(wy, rows[t][k], v[k]);
-	}
+		for (int k = 0; k < 4; ++k) v[k] = __builtin_elementwise_fma(wy[t], rows[t][k], v[k]);
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
@@ -242,7 +283,9 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 	constexpr int T = TAPS;
 	constexpr int NP = NW + 3;                      /* pixels of the 8 that carry weight */
 	const int j = r & 63;
+	STAMP(0);                                       /* everything outside blocks */
 	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j + NR - 1));
+	STAMP(1);                                       /* fetch: DMA issue + wait */
 	const int nR = rrl(st.t_rb[0], j) + T - 1, nB = rrl(st.t_rb[1], j) + T - 1;   /* newest row of output row r */
 
 	u32x4 idt[NR], pr[NR], pb[NR];
@@ -252,6 +295,10 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 		pb[n] = roll_ring_win(st, nB + n, st.tap[1]);
 		idt[n] = roll_ring_px(st, y + n, st.my_idt);
 	}
+	f32x2 acc[NR][4], wy[NR][T];
+#pragma unroll
+	for (int n = 0; n < NR; ++n) roll_wy<TAPS>(st, j + n, wy[n]);
+	STAMP(2);                                       /* ring + weight reads issued and landed */
 	f32x2 rows[T - 1 + NR][4];                      /* hist rows, then the NR new rows */
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
@@ -267,8 +314,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 			tp[n][k] = f32x2{ (float)(pr[n][k] & 0xffu), (float)((pb[n][k] >> 16) & 0xffu) };
 #pragma unroll
 		for (int k = 4; k < NP; ++k) {
-			const uint32_t nr = next_lane(pr[n][k - 4]), nb = next_lane(pb[n][k - 4]);
-			tp[n][k] = f32x2{ (float)(nr & 0xffu), (float)((nb >> 16) & 0xffu) };
+			tp[n][k] = f32x2{ next_lane_ubyte0(pr[n][k - 4]), next_lane_ubyte2(pb[n][k - 4]) };
 		}
 	}
 #pragma unroll
@@ -281,22 +327,29 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 				                              : __builtin_elementwise_fma(wx[i][t], tp[n][i + t], rows[T - 1 + n][i]);
 
 	/* vertical: acc[n][k] = bias + sum_t wy[n][t] * rows[n + t][k] */
-	f32x2 acc[NR][4];
 #pragma unroll
 	for (int t = 0; t < T; ++t)
 #pragma unroll
-		for (int n = 0; n < NR; ++n) {
-			const f32x2 wy = { rrlf(st.t_wy[0][t], j + n), rrlf(st.t_wy[1][t], j + n) };
+		for (int n = 0; n < NR; ++n)
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
-				acc[n][k] = __builtin_elementwise_fma(wy, rows[n + t][k], (t == 0) ? f32x2{ ROUND_BIAS, ROUND_BIAS } : acc[n][k]);
-		}
+				acc[n][k] = __builtin_elementwise_fma(wy[n][t], rows[n + t][k], (t == 0) ? f32x2{ ROUND_BIAS, ROUND_BIAS } : acc[n][k]);
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
 		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[NR + t][k];
+#if defined(FIXCA_EXP_STAMPS)
+	{ float sink = 0.f;                             /* make the arithmetic finish before the stamp */
+#pragma unroll
+	  for (int n = 0; n < NR; ++n)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) sink += acc[n][k].x + acc[n][k].y;
+	  asm volatile("v_readfirstlane_b32 s0, %0" :: "v"(sink) : "s0"); }
+#endif
+	STAMP(3);                                       /* filter arithmetic */
 #pragma unroll
 	for (int n = 0; n < NR; ++n) roll_store(st, acc[n], idt[n]);
+	STAMP(4);                                       /* conversions + stores */
 }
 
 template <int TAPS>          /* 2 = LINEAR, 4 = CUBIC */
@@ -318,11 +371,17 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	const int nrows = min(pl.th, g.y2 - Y0);
 
 	RollState<TAPS> st;
+#if defined(FIXCA_EXP_STAMPS)
+	st.last = __builtin_amdgcn_s_memtime();
+	const unsigned long long t_begin = st.last;
+	for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+#endif
 	st.lane = lane;
 	st.KM = pl.ring - 1;                            /* ring rows: power of two */
 	st.H = H;
 	st.pitch = (uint32_t)W * 4u;
 	st.ring = lds + RING_PAD_LO;
+	st.wtab = lds + RING_PAD_LO + (size_t)pl.ring * RING_ROW + RING_PAD_HI;
 	{
 		/* descriptors are built from kernel arguments only, so they are provably wave-uniform */
 		const uint32_t total = (uint32_t)W * (uint32_t)H * 4u;      /* < 4 GB: the planner checks */
@@ -348,9 +407,10 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 		const int yr = min(Y0 + rbase + lane, H - 1);
 		int keep = yr, need = yr;
 		bool reg = (rbase + lane) > 0;
+		float wyl[2][T];
 #pragma unroll
 		for (int c = 0; c < 2; ++c) {
-			row_of(yr, c, st.t_rb[c], st.t_wy[c]);
+			row_of(yr, c, st.t_rb[c], wyl[c]);
 			int prev;
 			row_of(max(yr - 1, 0), c, prev, nullptr);
 			reg = reg && (st.t_rb[c] == prev + 1) && (st.t_rb[c] >= 0) && (st.t_rb[c] + T - 1 <= H - 1);
@@ -360,6 +420,18 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 		st.t_keep = keep;
 		st.t_need = need;
 		st.regmask = __ballot(reg);
+		/* my row's weights into the table (LDS operations of one wave execute in order; the
+		 * fences only keep the compiler from moving reads across the writes) */
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		float *wt = reinterpret_cast<float *>(st.wtab + lane * 32);
+#pragma unroll
+		for (int t = 0; t < T; ++t) {
+			wt[2 * t] = wyl[0][t];
+			wt[2 * t + 1] = wyl[1][t];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	};
 
 	/* the last source row this wave will ever need */
@@ -377,8 +449,6 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 
 	build_rows(0);
 	st.ld = rrl(st.t_keep, 0) - 1;
-	st.seq = 0;
-	st.seqtab = 0;
 	st.vo_ld = (uint32_t)(U0 + 4 * lane) * 4u;
 	st.so_ld = (uint32_t)(st.ld + 1) * st.pitch;
 	/* start filling the ring before the (fp64-heavy) lane constants are computed */
@@ -507,8 +577,22 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 			}
 		}
 	};
+#if defined(FIXCA_EXP_STAMPS)
+	STAMP(5);                                       /* prologue */
+#endif
 	if (gen) run(std::integral_constant<int, 5>{});
 	else     run(std::integral_constant<int, T>{});
+#if defined(FIXCA_EXP_STAMPS)
+	STAMP(0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (lane < 8) {
+		unsigned long long v = st.acc[0];
+		for (int i = 1; i < 8; ++i) v = (lane == i) ? st.acc[i] : v;
+		if (lane == 6) v = st.last - t_begin;
+		if (lane == 7) v = gen;
+		reinterpret_cast<unsigned long long *>(dst)[(size_t)tile * 8 + lane] = v;
+	}
+#endif
 }
 
 extern "C" hipError_t
@@ -516,7 +600,7 @@ fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 {
 	const uint8_t *s = static_cast<const uint8_t *>(d_src);
 	uint8_t *d = static_cast<uint8_t *>(d_dst);
-	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
+	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI + 64 * 32;
 	static bool attr_done = false;
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void *)k_roll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_PKG), "libfixca_hip.so")
+_LIB_PATH = os.environ.get("FIXCA_LIB") or os.path.join(os.path.dirname(_PKG), "libfixca_hip.so")   # FIXCA_LIB: timing-experiment builds
 
 INTERP_NONE, INTERP_LINEAR, INTERP_CUBIC = 0, 1, 2
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_FAST = 0, 1, 2

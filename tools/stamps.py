@@ -1,0 +1,28 @@
+"""Timing experiment (GPU box): run the FIXCA_EXP_STAMPS build of k_roll once and print where
+a wave's cycles go.  FIXCA_LIB must point at the stamped library (tools/bin/v_stamps)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gimp-fix-ca_amd"))
+import torch, fixca
+W, H = 6000, 4000
+interp = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=interp)
+kid, desc = fixca.plan(W, H, 4, 1, p)
+print(desc)
+nw = int(desc.split("waves=")[1])
+src = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device="cuda")
+dst = torch.empty_like(src)
+for _ in range(3):
+    fixca.fix_ca_region(src, dst, W, H, 4, 1, p, 0, W, 0, H, True)
+torch.cuda.synchronize()
+a = dst.view(-1)[: nw * 64].cpu().numpy().view(np.uint64).reshape(nw, 8).astype(np.float64)
+names = ["outside blocks", "fetch (DMA issue + vm wait)", "LDS reads issued+landed", "filter arithmetic", "convert + store issue", "prologue", "TOTAL wave", "gen"]
+tot = a[:, 6]
+print("waves", nw, " mean total cycles (memtime ticks) %.0f  min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
+for i in range(6):
+    print("  %-30s %9.0f  %5.1f %%" % (names[i], a[:, i].mean(), 100 * a[:, i].mean() / tot.mean()))
+print("  gen-path waves: %.1f %%" % (100 * a[:, 7].mean()))
+g = a[:, 7] > 0
+if g.any() and (~g).any():
+    print("  total fast-path waves %.0f, general-path waves %.0f" % (tot[~g].mean(), tot[g].mean()))
