@@ -138,8 +138,11 @@ extern "C" int fixca_batch_device(const void *const *d_src, void *const *d_dst, 
 static void  *g_cache[2] = { NULL, NULL };
 static size_t g_cache_bytes = 0;
 
+extern "C" void fixca_roll_release_tables(void);
+
 extern "C" void fixca_release_cache(void)
 {
+	fixca_roll_release_tables();
 	for (int i = 0; i < 2; ++i) {
 		if (g_cache[i]) (void)hipFree(g_cache[i]);
 		g_cache[i] = NULL;

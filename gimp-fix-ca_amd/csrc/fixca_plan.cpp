@@ -318,8 +318,8 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 		 * first window); a row time grows with the k = ceil(waves / 256) waves sharing a CU about
 		 * as 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9): mostly latency, partly
 		 * throughput. */
-		int per_cu = (160 * 1024) / (ring * 1024 + 2560);   /* ring + pads + the 2 KB weight table */
-		if (per_cu > 8) per_cu = 8;
+		int per_cu = (160 * 1024) / (ring * 1024 + 512);
+		if (per_cu > 7) per_cu = 7;                     /* measured: 7 waves per CU beat 8 and 9 at equal total rows */
 		int best_th = 0;
 		long best_cost = 0;
 		for (int th = 16; th <= 1024; ++th) {

@@ -1,0 +1,35 @@
+/*
+ * fixca_roll.h — tables the row-rolling kernel reads (built by k_roll_tables in fixca_roll.hip,
+ * once per geometry and parameter block).  Plain structs, shared by the two kernels and the
+ * launcher.
+ */
+#ifndef FIXCA_ROLL_H
+#define FIXCA_ROLL_H
+
+#include <stdint.h>
+
+/* one strip of `oc` output columns (16 bytes) */
+struct RollStrip {
+	int U0;             /* first column of the 256-column source window (multiple of 4)          */
+	int tapR, tapB;     /* byte offset, in a ring row, of lane 0's 4-pixel tap window (may be < 0) */
+	int gen;            /* 1: some output of the strip needs the 5th weight (step or image edge)  */
+};
+
+/* one output row y, seen as the first row of a block (32 bytes) */
+struct RollBlock {
+	int rb[2];          /* first (virtual) source row of the red / blue window: floor(y') - BACK   */
+	int keep;           /* oldest source row output row y touches                                  */
+	int need1;          /* newest source row output row y touches                                  */
+	int need4;          /* newest source row output rows y .. y+3 touch                            */
+	int reg4;           /* bit n: both windows of row y+n slide down by exactly one unclamped row   */
+	int pad[2];
+};
+
+struct RollTables {
+	RollStrip *strips;  /* [nstrips]                                                               */
+	float     *colw;    /* [nstrips][10][64 lanes][4]: a lane's 5 x 4 (red, blue) tap weights        */
+	RollBlock *blocks;  /* [H]                                                                     */
+	float     *roww;    /* [H][8]: (red, blue) vertical weights of tap 0..3                          */
+};
+
+#endif

@@ -6,30 +6,36 @@
  *   HBM/L2 --LDS-DMA--> ring of K source rows in LDS --> registers --> HBM
  *
  * one wave (a 64-thread workgroup) owns `oc` output columns x `th` output rows, streams every
- * source row of its 256-column window into LDS once with global_load_lds_dwordx4 and waits for
+ * source row of its 256-column window into LDS once with buffer_load ... lds and waits for
  * exactly the row it needs with a counted s_waitcnt vmcnt.  What differs is the filter:
  *
  *  - HORIZONTAL FIRST, straight from the ring, no exchange through LDS.  The map is
  *    x' = (x - xc)*s + xc - shift with s within a fraction of a percent of 1, so over one strip the
  *    first tap of output column x sits at x + m or x + m + 1 for one strip constant m.  Lane L
- *    reads the 4 ring pixels [P + 4L, P + 4L + 4) (one 16-byte LDS read per channel and source
- *    row; P = m relative to the window) and takes the next 4 from lane L + 1 with a DPP
- *    wave-shift folded into the byte->float conversion (v_cvt_f32_ubyteN_dpp wave_shl:1): 8 pixels
- *    in registers, no data crosses LDS a second time.  The "+1" steps, and the reference's edge
- *    clamping (fix-ca.c:1270-1298), are folded into the lane's tap weights: output i uses
- *    pixels i .. i+4 of the 8 with 5 weights of which at most T are non-zero (clamped taps add
- *    their weights on the clamped column).  Waves whose strip has no step and touches no edge
- *    (most of them) run a T-tap loop instead.
+ *    reads the 4 ring pixels [P + 4L, P + 4L + 4) (per channel and source row; P = m relative to
+ *    the window) and takes the next 4 from lane L + 1 with a DPP wave-shift folded into the
+ *    byte->float conversion (v_cvt_f32_ubyteN_dpp wave_shl:1): 8 pixels in registers, no data
+ *    crosses LDS a second time.  The "+1" steps, and the reference's edge clamping
+ *    (fix-ca.c:1270-1298), are folded into the lane's tap weights: output i uses pixels
+ *    i .. i+4 of the 8 with 5 weights of which at most T are non-zero (clamped taps add their
+ *    weights on the clamped column).  Waves whose strip has no step and touches no edge (most
+ *    of them) run a T-tap loop instead.
  *  - The horizontally filtered row of each channel (4 floats per lane, red and blue packed in
  *    f32x2 for v_pk_fma_f32) enters a rolling window of T rows in registers; the vertical
- *    filter (fix-ca.c:911-920) is T packed FMAs per pixel with wave-uniform weights.
- *    This is the reference's own order: cubicY across columns, then cubicX across rows.
- *  - Per-row values (source rows, vertical weights, ring bounds) are computed once per wave,
- *    one output row per lane, and broadcast with v_readlane.
+ *    filter (fix-ca.c:911-920) is T packed FMAs per pixel with wave-uniform weights held in
+ *    SGPRs.  This is the reference's own order: cubicY across columns, then cubicX across rows.
+ *  - The kernel is bound by vector-instruction issue (one instruction per ~4.3 cycles per SIMD
+ *    whatever the mix; measured), not by LDS, waits or HBM, so everything that does not depend
+ *    on the pixels is taken out of it: a small table kernel (k_roll_tables, once per geometry
+ *    and parameter block, cached by the launcher) computes
+ *        per strip   the ring window, the two tap offsets and the general/T-tap choice,
+ *        per lane    the 5 x 4 (red, blue) tap weights,
+ *        per row     source rows, ring bounds, "slides by one" flags and vertical weights,
+ *    with the reference's fp64 coordinate arithmetic, and the row loop reads them with
+ *    coalesced vector loads (once per wave) and scalar loads (per block of 4 rows).
  *
  * fp32 sample arithmetic on fp64 coordinates: within 1 LSB of the reference; green and alpha
- * are copied bit-exactly.  Per output row and lane: 3 LDS reads, ~60 vector ALU operations,
- * one 16-byte store; no barrier, no LDS write by the wave itself.
+ * are copied bit-exactly.
  *
  * The planner (fixca_plan.cpp, plan_roll) selects this kernel when W % 4 == 0, W >= 256, every
  * strip's union window fits 256 columns, its tap offsets drift by at most one column and the
@@ -37,9 +43,12 @@
  * fixca_kernels.hip.
  */
 #include "fixca_device.h"
+#include "fixca_roll.h"
+#include <string.h>
 #include <type_traits>
 
 typedef float        f32x2 __attribute__((ext_vector_type(2)));
+typedef float        f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -58,16 +67,33 @@ template <int N> __device__ __forceinline__ void roll_wait_vm()
 }
 
 __device__ __forceinline__ int rclampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }
-__device__ __forceinline__ int rrl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float rrlf(float v, int lane)
+
+/* scalar (SMEM) loads: the tables are read-only for the whole launch and every address below
+ * is wave-uniform; the constant address space makes hipcc emit s_load_dword* */
+typedef const __attribute__((address_space(4))) int   *cint_p;
+typedef const __attribute__((address_space(4))) float *cfloat_p;
+
+__device__ __forceinline__ RollStrip load_strip(cint_p strips, int i)
 {
-	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+	cint_p p = strips + (size_t)i * (sizeof(RollStrip) / 4);
+	RollStrip h;
+	h.U0 = p[0]; h.tapR = p[1]; h.tapB = p[2]; h.gen = p[3];
+	return h;
+}
+__device__ __forceinline__ RollBlock load_block(cint_p blocks, int y)
+{
+	cint_p p = blocks + (size_t)y * (sizeof(RollBlock) / 4);
+	RollBlock b;
+	b.rb[0] = p[0]; b.rb[1] = p[1]; b.keep = p[2]; b.need1 = p[3]; b.need4 = p[4]; b.reg4 = p[5];
+	b.pad[0] = b.pad[1] = 0;
+	return b;
 }
 
 /* byte 0 / byte 2 of the dword lane L + 1 holds, as a float (0 in lane 63): the byte->float
  * conversion with a DPP wave shift as its operand modifier.  Written as asm because hipcc folds
  * the shift into the conversion only in some schedules and otherwise spends two extra moves per
- * pixel.  No DPP hazard arises: the source registers are written by LDS loads, not by VALU. */
+ * pixel.  No DPP hazard arises: the source registers are written by LDS loads, not by VALU
+ * (tests/test_isa_checks.py looks at the generated code). */
 __device__ __forceinline__ float next_lane_ubyte0(uint32_t v)
 {
 	float f;
@@ -96,15 +122,8 @@ struct RollState {
 	unsigned long long last, acc[8];
 #endif
 	static constexpr int T = TAPS;
-	int      lane;
-	bool     active;
 	int      tap[2];            /* byte offset (may be negative) of my 4-pixel window in a ring row */
 	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
-	/* row table: lane j describes output row Y0 + 64*blk + j */
-	int      t_rb[2], t_keep, t_need;
-	uint8_t *wtab;              /* LDS: vertical weights of the 64 rows of the table, row j at 32*j:
-	                               (red, blue) of tap 0, tap 1, ... as f32x2; v_readlane costs 3x a VALU op */
-	unsigned long long regmask; /* bit j: both windows of row j slide down by exactly one unclamped row */
 	/* ring */
 	uint8_t *ring;
 	int      KM, H;
@@ -115,7 +134,7 @@ struct RollState {
 	 * offset outside the buffer (dropped by the range check) instead of a branch */
 	rsrc_t   rs_src, rs_dst;
 	uint32_t vo_ld;             /* my byte offset inside a source row segment                   */
-	uint32_t vo_st;             /* my byte offset inside an output row, ~0 if I produce nothing */
+	uint32_t vo_st;             /* my byte offset inside an output row, past the end if I produce nothing */
 	uint32_t so_ld;             /* byte offset of source row ld + 1                             */
 	uint32_t so_st;             /* byte offset of the next output row                           */
 	uint32_t pitch;
@@ -153,7 +172,8 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS> &st, int keep, int ne
 	return;
 #endif
 	const int younger = st.ld - need;
-	if (younger >= 6) roll_wait_vm<6>();
+	if (younger >= 8) roll_wait_vm<8>();
+	else if (younger >= 6) roll_wait_vm<6>();
 	else if (younger >= 4) roll_wait_vm<4>();
 	else if (younger >= 2) roll_wait_vm<2>();
 	else roll_wait_vm<0>();
@@ -181,6 +201,18 @@ __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS> &st, int ro
 #endif
 }
 
+/* the 8 (NP used) pixels of my window of one source row per channel, as (red, blue) floats */
+template <int NP>
+__device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, f32x2 (&tp)[NP])
+{
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
+#pragma unroll
+	for (int k = 4; k < NP; ++k)
+		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
+}
+
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
  * h[i] = sum_t wx[i][t] * px8[i + t] for my 4 output columns */
 template <int TAPS, int NW>
@@ -189,15 +221,8 @@ __device__ __forceinline__ void roll_hrow(const RollState<TAPS> &st, const f32x2
 {
 	const u32x4 pr = roll_ring_win(st, rowR, st.tap[0]);
 	const u32x4 pb = roll_ring_win(st, rowB, st.tap[1]);
-	constexpr int NP = NW + 3;                      /* pixels of the 8 that carry weight */
-	f32x2 tp[NP];
-#pragma unroll
-	for (int k = 0; k < 4; ++k)
-		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
-#pragma unroll
-	for (int k = 4; k < NP; ++k) {
-		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
-	}
+	f32x2 tp[NW + 3];
+	roll_px8<NW + 3>(pr, pb, tp);
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		f32x2 a = wx[i][0] * tp[i];
@@ -207,18 +232,13 @@ __device__ __forceinline__ void roll_hrow(const RollState<TAPS> &st, const f32x2
 	}
 }
 
-/* the T (red, blue) vertical weight pairs of table row j: a broadcast LDS read */
+/* the T (red, blue) vertical weight pairs of output row y: scalar loads, the pairs stay in SGPRs */
 template <int TAPS>
-__device__ __forceinline__ void roll_wy(const RollState<TAPS> &st, int j, f32x2 (&wy)[TAPS])
+__device__ __forceinline__ void roll_wy(cfloat_p roww, int y, f32x2 (&wy)[TAPS])
 {
-	typedef float f32x4 __attribute__((ext_vector_type(4)));
-	const f32x4 *p = reinterpret_cast<const f32x4 *>(st.wtab + j * 32);
+	cfloat_p p = roww + (size_t)y * 8;
 #pragma unroll
-	for (int h = 0; h < TAPS / 2; ++h) {
-		const f32x4 q = p[h];
-		wy[2 * h] = f32x2{ q.x, q.y };
-		wy[2 * h + 1] = f32x2{ q.z, q.w };
-	}
+	for (int t = 0; t < TAPS; ++t) wy[t] = f32x2{ p[2 * t], p[2 * t + 1] };
 }
 
 /* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
@@ -245,22 +265,21 @@ __device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&ac
 /* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
  * window touches the top or bottom edge: edge rows replicate, fix-ca.c:1218-1256) */
 template <int TAPS, int NW>
-__device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&wx)[4][5], int r, int y)
+__device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
+                                             cfloat_p roww, int y)
 {
 	constexpr int T = TAPS;
-	const int j = r & 63;
-	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j));
+	roll_fetch(st, b.keep, b.need1);
 	const u32x4 idt = roll_ring_px(st, y, st.my_idt);
-	const int rbR = rrl(st.t_rb[0], j), rbB = rrl(st.t_rb[1], j);
 	f32x2 rows[T][4];
 #pragma unroll
 	for (int t = 0; t < T; ++t)
-		roll_hrow<TAPS, NW>(st, wx, rclampi(rbR + t, 0, st.H - 1), rclampi(rbB + t, 0, st.H - 1), rows[t]);
+		roll_hrow<TAPS, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
 	f32x2 v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
 	f32x2 wy[T];
-	roll_wy<TAPS>(st, j, wy);
+	roll_wy<TAPS>(roww, y, wy);
 #pragma unroll
 	for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -272,21 +291,20 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&
 	roll_store(st, v, idt);
 }
 
-/* NR (1..4) consecutive output rows whose windows each slide down by one unclamped source row.
+/* NR (1 or 4) consecutive output rows whose windows each slide down by one unclamped source row.
  * All ring reads of the rows are issued together; the filter arithmetic is written tap-major
  * (for each tap, all rows and outputs) so that consecutive instructions belong to different
- * accumulation chains: a wave shares its SIMD with one or two others at most and has to cover
- * its own FMA latency. */
+ * accumulation chains. */
 template <int TAPS, int NW, int NR>
-__device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx)[4][5], int r, int y)
+__device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
+                                           const RollBlock &bn, cfloat_p roww, int y)
 {
 	constexpr int T = TAPS;
 	constexpr int NP = NW + 3;                      /* pixels of the 8 that carry weight */
-	const int j = r & 63;
 	STAMP(0);                                       /* everything outside blocks */
-	roll_fetch(st, rrl(st.t_keep, j), rrl(st.t_need, j + NR - 1));
+	roll_fetch(st, b.keep, NR == 4 ? b.need4 : b.need1);
 	STAMP(1);                                       /* fetch: DMA issue + wait */
-	const int nR = rrl(st.t_rb[0], j) + T - 1, nB = rrl(st.t_rb[1], j) + T - 1;   /* newest row of output row r */
+	const int nR = b.rb[0] + T - 1, nB = b.rb[1] + T - 1;   /* newest row of output row y */
 
 	u32x4 idt[NR], pr[NR], pb[NR];
 #pragma unroll
@@ -297,8 +315,17 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 	}
 	f32x2 acc[NR][4], wy[NR][T];
 #pragma unroll
-	for (int n = 0; n < NR; ++n) roll_wy<TAPS>(st, j + n, wy[n]);
-	STAMP(2);                                       /* ring + weight reads issued and landed */
+	for (int n = 0; n < NR; ++n) roll_wy<TAPS>(roww, y + n, wy[n]);
+	/* Everything this block needs from the ring is now in registers (after the wait), so the
+	 * slots of rows the NEXT block no longer touches are free already: refill them now, and the
+	 * loads travel while this block computes.  Issuing only at block boundaries would leave the
+	 * wave with no load in flight for most of a block. */
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	{
+		const int target = min(min(bn.need4 + RDEPTH, bn.keep + st.KM), st.lastneed);
+		while (st.ld < target) roll_issue(st);
+	}
+	STAMP(2);                                       /* ring reads issued and landed */
 	f32x2 rows[T - 1 + NR][4];                      /* hist rows, then the NR new rows */
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
@@ -308,15 +335,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
 #pragma unroll
-	for (int n = 0; n < NR; ++n) {
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-			tp[n][k] = f32x2{ (float)(pr[n][k] & 0xffu), (float)((pb[n][k] >> 16) & 0xffu) };
-#pragma unroll
-		for (int k = 4; k < NP; ++k) {
-			tp[n][k] = f32x2{ next_lane_ubyte0(pr[n][k - 4]), next_lane_ubyte2(pb[n][k - 4]) };
-		}
-	}
+	for (int n = 0; n < NR; ++n) roll_px8<NP>(pr[n], pb[n], tp[n]);
 #pragma unroll
 	for (int t = 0; t < NW; ++t)
 #pragma unroll
@@ -354,11 +373,10 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 
 template <int TAPS>          /* 2 = LINEAR, 4 = CUBIC */
 __global__ __launch_bounds__(64) void
-k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, FixcaPlan pl)
+k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, FixcaPlan pl, RollTables tb)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	constexpr int T = TAPS;
-	constexpr int BACK = (TAPS == 4) ? 1 : 0;
 
 	const int lane = threadIdx.x;
 	const int tile = xcd_remap(blockIdx.x, pl.nblocks);
@@ -374,100 +392,181 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 #if defined(FIXCA_EXP_STAMPS)
 	st.last = __builtin_amdgcn_s_memtime();
 	const unsigned long long t_begin = st.last;
+	const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 	for (int i = 0; i < 8; ++i) st.acc[i] = 0;
 #endif
-	st.lane = lane;
 	st.KM = pl.ring - 1;                            /* ring rows: power of two */
 	st.H = H;
 	st.pitch = (uint32_t)W * 4u;
 	st.ring = lds + RING_PAD_LO;
-	st.wtab = lds + RING_PAD_LO + (size_t)pl.ring * RING_ROW + RING_PAD_HI;
 	{
 		/* descriptors are built from kernel arguments only, so they are provably wave-uniform */
-		const uint32_t total = (uint32_t)W * (uint32_t)H * 4u;      /* < 4 GB: the planner checks */
+		const uint32_t total = (uint32_t)W * (uint32_t)H * 4u;      /* <= 2 GB: the planner checks */
 		st.rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, total, 0x00020000);
 		st.rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total, 0x00020000);
 	}
 
-	/* ---- the 256-column source window of this strip (wave-uniform) ------------------- */
+	/* ---- tables: strip header, first and last block descriptor (scalar loads) ------------ */
+	const cint_p strips = (cint_p)(const int *)tb.strips;
+	const cint_p blocks = (cint_p)(const int *)tb.blocks;
+	const cfloat_p roww = (cfloat_p)tb.roww;
+	const RollStrip hd = load_strip(strips, strip);
+	RollBlock b = load_block(blocks, Y0);
+	st.lastneed = load_block(blocks, Y0 + nrows - 1).need1;
+	const int U0 = hd.U0;
+
+	/* start filling the ring before anything else */
+	st.ld = b.keep - 1;
+	st.vo_ld = (uint32_t)(U0 + 4 * lane) * 4u;
+	st.so_ld = (uint32_t)b.keep * st.pitch;
+	{
+		const int target = min(min(b.need1 + RDEPTH, b.keep + st.KM), st.lastneed);
+		while (st.ld < target) roll_issue(st);
+	}
+
+	/* ---- per-lane tap weights: 10 coalesced 16-byte loads ---------------------------------- */
+	const int nact = oc >> 2;                        /* lanes that produce output */
+	f32x2 wx[4][5];
+	{
+		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
+		float f[40];
+#pragma unroll
+		for (int q = 0; q < 10; ++q) {
+			const f32x4 v = cw[q * 64];
+			f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int jj = 0; jj < 5; ++jj) wx[i][jj] = f32x2{ f[(i * 5 + jj) * 2], f[(i * 5 + jj) * 2 + 1] };
+	}
+	st.tap[0] = hd.tapR + 16 * lane;
+	st.tap[1] = hd.tapB + 16 * lane;
+	st.my_idt = (uint32_t)((X0 - U0) * 4) + (uint32_t)min(lane, nact - 1) * 16;
+	/* a lane without output stores at offset `total`: past the end whether or not the range check
+	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
+	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * 4u : (uint32_t)W * (uint32_t)H * 4u;
+	st.so_st = (uint32_t)Y0 * st.pitch;
+
+	auto run = [&](auto nw_tag) {
+		constexpr int NW = decltype(nw_tag)::value;
+		int r = 0;
+		while (r < nrows) {
+			const int y = Y0 + r;
+			const bool four = r > 0 && r + 3 < nrows && (b.reg4 & 0xF) == 0xF;
+			const bool one = r > 0 && (b.reg4 & 1);      /* tails and rows next to an irregular one */
+			const int step = four ? 4 : 1;
+			/* the next descriptor is requested before this block's work: its scalar load has the
+			 * whole block to come back */
+			RollBlock bn = b;
+			if (r + step < nrows) bn = load_block(blocks, y + step);
+			if (four)     roll_block<TAPS, NW, 4>(st, wx, b, bn, roww, y);
+			else if (one) roll_block<TAPS, NW, 1>(st, wx, b, bn, roww, y);
+			else          roll_row_any<TAPS, NW>(st, wx, b, roww, y);
+			r += step;
+			b = bn;
+		}
+	};
+#if defined(FIXCA_EXP_STAMPS)
+	STAMP(5);                                       /* prologue */
+#endif
+	if (hd.gen) run(std::integral_constant<int, 5>{});
+	else        run(std::integral_constant<int, T>{});
+#if defined(FIXCA_EXP_STAMPS)
+	STAMP(0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (lane < 8) {
+		unsigned long long v = st.acc[0];
+		for (int i = 1; i < 8; ++i) v = (lane == i) ? st.acc[i] : v;
+		if (lane == 6) v = st.last - t_begin;
+		if (lane == 7) v = hd.gen;
+		if (lane == 5) v = __builtin_amdgcn_s_memrealtime() - rt_begin;   /* 100 MHz ticks; replaces the prologue slot */
+		if (lane == 4) v = rt_begin;
+		reinterpret_cast<unsigned long long *>(dst)[(size_t)tile * 8 + lane] = v;
+	}
+#endif
+}
+
+/* ======================================================================================
+ * k_roll_tables: everything k_roll needs that does not depend on the pixels.
+ * Workgroup b < nstrips builds strip b's header and lane weights; workgroup nstrips + k
+ * builds the block descriptors and vertical weights of rows 64k .. 64k+63.
+ * ====================================================================================== */
+template <int TAPS>
+__global__ __launch_bounds__(64) void
+k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
+{
+	constexpr int T = TAPS;
+	constexpr int BACK = (TAPS == 4) ? 1 : 0;
+	const int lane = threadIdx.x;
+	const int W = g.W, H = g.H, oc = pl.oc;
+
+	if ((int)blockIdx.x >= pl.nstrips) {
+		/* ---- rows ------------------------------------------------------------------------- */
+		const int y = ((int)blockIdx.x - pl.nstrips) * 64 + lane;
+		if (y >= H) return;
+		auto row_of = [&](int yy, int c, int &rb, float *wy) {
+			double yd = map_dbl(yy, g.yc, H, g.s[c], g.ys[c]);
+			int y0 = (int)floor(yd);
+			if (wy) tap_weights_f32<T>((float)(yd - (double)y0), wy);
+			rb = y0 - BACK;
+		};
+		auto describe = [&](int yy, int &rbR, int &rbB, int &keep, int &need, bool &reg, float (*wy)[T]) {
+			int rb[2];
+			keep = yy; need = yy; reg = yy > 0;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				row_of(yy, c, rb[c], wy ? wy[c] : nullptr);
+				int prev;
+				row_of(max(yy - 1, 0), c, prev, nullptr);
+				reg = reg && (rb[c] == prev + 1) && (rb[c] >= 0) && (rb[c] + T - 1 <= H - 1);
+				keep = min(keep, rclampi(rb[c], 0, H - 1));
+				need = max(need, rclampi(rb[c] + T - 1, 0, H - 1));
+			}
+			rbR = rb[0]; rbB = rb[1];
+		};
+		float wy[2][T];
+		RollBlock b;
+		bool reg;
+		describe(y, b.rb[0], b.rb[1], b.keep, b.need1, reg, wy);
+		b.need4 = b.need1;
+		b.reg4 = reg ? 1 : 0;
+		for (int n = 1; n < 4; ++n) {
+			if (y + n > H - 1) break;
+			int r0, r1, kp, nd;
+			bool rg;
+			describe(y + n, r0, r1, kp, nd, rg, nullptr);
+			b.need4 = max(b.need4, nd);
+			b.reg4 |= rg ? (1 << n) : 0;
+		}
+		b.pad[0] = b.pad[1] = 0;
+		tb.blocks[y] = b;
+		float *w = tb.roww + (size_t)y * 8;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			w[2 * t] = t < T ? wy[0][t < T ? t : 0] : 0.f;
+			w[2 * t + 1] = t < T ? wy[1][t < T ? t : 0] : 0.f;
+		}
+		return;
+	}
+
+	/* ---- one strip ------------------------------------------------------------------------ */
+	const int strip = blockIdx.x;
+	int X0 = strip * oc;
+	if (X0 > W - oc) X0 = W - oc;
 	int lo = X0;
 #pragma unroll
 	for (int c = 0; c < 2; ++c)
 		lo = min(lo, rclampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1));
-	const int U0 = __builtin_amdgcn_readfirstlane(min(lo & ~3, W - FIXCA_WAVE_COLS));
+	const int U0 = min(lo & ~3, W - FIXCA_WAVE_COLS);
 
-	/* ---- row mapping (shared by the row table and the bounds below) ------------------- */
-	auto row_of = [&](int y, int c, int &rb, float *wy) {
-		double yd = map_dbl(y, g.yc, H, g.s[c], g.ys[c]);
-		int y0 = (int)floor(yd);
-		if (wy) tap_weights_f32<T>((float)(yd - (double)y0), wy);
-		rb = y0 - BACK;
-	};
-	auto build_rows = [&](int rbase) {               /* lane j <- output row Y0 + rbase + j */
-		const int yr = min(Y0 + rbase + lane, H - 1);
-		int keep = yr, need = yr;
-		bool reg = (rbase + lane) > 0;
-		float wyl[2][T];
-#pragma unroll
-		for (int c = 0; c < 2; ++c) {
-			row_of(yr, c, st.t_rb[c], wyl[c]);
-			int prev;
-			row_of(max(yr - 1, 0), c, prev, nullptr);
-			reg = reg && (st.t_rb[c] == prev + 1) && (st.t_rb[c] >= 0) && (st.t_rb[c] + T - 1 <= H - 1);
-			keep = min(keep, rclampi(st.t_rb[c], 0, H - 1));
-			need = max(need, rclampi(st.t_rb[c] + T - 1, 0, H - 1));
-		}
-		st.t_keep = keep;
-		st.t_need = need;
-		st.regmask = __ballot(reg);
-		/* my row's weights into the table (LDS operations of one wave execute in order; the
-		 * fences only keep the compiler from moving reads across the writes) */
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		float *wt = reinterpret_cast<float *>(st.wtab + lane * 32);
-#pragma unroll
-		for (int t = 0; t < T; ++t) {
-			wt[2 * t] = wyl[0][t];
-			wt[2 * t + 1] = wyl[1][t];
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	};
-
-	/* the last source row this wave will ever need */
-	{
-		const int yl = Y0 + nrows - 1;
-		int ln = yl;
-#pragma unroll
-		for (int c = 0; c < 2; ++c) {
-			int rb;
-			row_of(yl, c, rb, nullptr);
-			ln = max(ln, rclampi(rb + T - 1, 0, H - 1));
-		}
-		st.lastneed = __builtin_amdgcn_readfirstlane(ln);
-	}
-
-	build_rows(0);
-	st.ld = rrl(st.t_keep, 0) - 1;
-	st.vo_ld = (uint32_t)(U0 + 4 * lane) * 4u;
-	st.so_ld = (uint32_t)(st.ld + 1) * st.pitch;
-	/* start filling the ring before the (fp64-heavy) lane constants are computed */
-	{
-		const int keep0 = rrl(st.t_keep, 0), need0 = rrl(st.t_need, 0);
-		const int target = min(min(need0 + RDEPTH, keep0 + st.KM), st.lastneed);
-		while (st.ld < target) roll_issue(st);
-	}
-
-	/* ---- per-lane column constants ------------------------------------------------ */
 	const int nact = oc >> 2;                        /* lanes that produce output */
-	st.active = lane < nact;
+	const bool active = lane < nact;
 	const int xl = X0 + 4 * min(lane, nact - 1);     /* first output column of this lane */
 
 	/* tap columns (clamped as the reference clamps them) and weights of my 4 outputs */
 	int   col[2][4][T];
 	float wt[2][4][T];
-	bool  whole[2][4];                               /* fraction != 0: all T taps carry weight */
-	bool  plain = true;                              /* every output: whole, and T consecutive unclamped columns */
 	int   mlo[2] = { 1 << 30, 1 << 30 };             /* min over the strip of (tap column - x), taps with weight */
 #pragma unroll
 	for (int c = 0; c < 2; ++c)
@@ -491,16 +590,14 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 			 * edge does) has all its weight on that column; its other taps, which may lie far
 			 * from the rest of the strip's, do not count.  Host and device take this decision on
 			 * the fp64 fraction, where they agree bit for bit. */
-			whole[c][i] = (fx != 0.0);
 			constexpr int CT = (T == 4) ? 1 : 0;                    /* the tap with weight 1 at fraction 0 */
-			if (whole[c][i]) {
+			if (fx != 0.0) {
 				mlo[c] = min(mlo[c], col[c][i][0] - x);
 			} else {
 				mlo[c] = min(mlo[c], col[c][i][CT] - x);
 #pragma unroll
 				for (int t = 0; t < T; ++t) wt[c][i][t] = (t == CT) ? 1.0f : 0.0f;
 			}
-			plain = plain && whole[c][i] && (col[c][i][T - 1] - col[c][i][0] == T - 1);
 		}
 	/* strip minimum: butterfly over the wave (inactive lanes carry copies of lane nact-1) */
 #pragma unroll
@@ -510,89 +607,130 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 		mlo[c] = __builtin_amdgcn_readfirstlane(mlo[c]);
 	}
 
-	/* fold steps and clamped taps into 5 weights per output: pixel i + j of my 8 has column
+	/* fold steps and clamped taps into 5 weights per output: pixel i + j of the lane's 8 has column
 	 * X0 + mlo + 4*lane + i + j, so tap t of output i lands on j = col - x - mlo, 0 <= j <= 4
 	 * for every tap with weight (the planner guarantees the range) */
-	f32x2 wx[4][5];
+	float wx[4][5][2];
 	bool gen = false;
-	if (__all(plain)) {
-		/* the usual strip: output i's taps are pixels i+k .. i+k+T-1 with k = 0 or a step */
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const int kR = col[0][i][0] - (xl + i) - mlo[0], kB = col[1][i][0] - (xl + i) - mlo[1];
-			gen = gen || kR != 0 || kB != 0;
+	for (int i = 0; i < 4; ++i)
 #pragma unroll
-			for (int jj = 0; jj < 5; ++jj) {
-				float a0 = 0.f, a1 = 0.f;
+		for (int jj = 0; jj < 5; ++jj) {
+			float a[2] = { 0.f, 0.f };
+#pragma unroll
+			for (int c = 0; c < 2; ++c)
 #pragma unroll
 				for (int t = 0; t < T; ++t)
-					if (jj - t >= 0 && jj - t <= 5 - T) {
-						a0 = (kR == jj - t) ? wt[0][i][t] : a0;
-						a1 = (kB == jj - t) ? wt[1][i][t] : a1;
-					}
-				wx[i][jj] = f32x2{ a0, a1 };
-			}
+					a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
+			wx[i][jj][0] = a[0];
+			wx[i][jj][1] = a[1];
+			if (jj >= T) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
 		}
-	} else {
-#pragma unroll
-		for (int i = 0; i < 4; ++i)
-#pragma unroll
-			for (int jj = 0; jj < 5; ++jj) {
-				float a[2] = { 0.f, 0.f };
-#pragma unroll
-				for (int c = 0; c < 2; ++c)
-#pragma unroll
-					for (int t = 0; t < T; ++t)
-						a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
-				wx[i][jj] = f32x2{ a[0], a[1] };
-				if (jj >= T) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
-			}
-	}
-	gen = __any(gen && st.active) != 0;
+	gen = __any(gen && active) != 0;
 
+	/* lane weights: 40 floats in the order (i, jj, channel), as 10 chunks of 16 bytes, chunk q of
+	 * all 64 lanes contiguous */
+	f32x4 *cw = reinterpret_cast<f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
 #pragma unroll
-	for (int c = 0; c < 2; ++c)
-		st.tap[c] = (X0 + mlo[c] - U0 + 4 * lane) * 4;
-	st.my_idt = (uint32_t)((X0 - U0) * 4) + (uint32_t)min(lane, nact - 1) * 16;
-	/* a lane without output stores at offset `total`: past the end whether or not the range check
-	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
-	st.vo_st = st.active ? (uint32_t)xl * 4u : (uint32_t)W * (uint32_t)H * 4u;
-	st.so_st = (uint32_t)Y0 * st.pitch;
-
-	auto run = [&](auto nw_tag) {
-		constexpr int NW = decltype(nw_tag)::value;
-		int r = 0;
-		while (r < nrows) {
-			const int j = r & 63;
-			if (r && j == 0) build_rows(r);
-			if (j + 3 < 64 && r + 3 < nrows && ((st.regmask >> j) & 0xFull) == 0xFull) {
-				roll_block<TAPS, NW, 4>(st, wx, r, Y0 + r);
-				r += 4;
-			} else if ((st.regmask >> j) & 1ull) {       /* tails and rows next to an irregular one */
-				roll_block<TAPS, NW, 1>(st, wx, r, Y0 + r);
-				r += 1;
-			} else {
-				roll_row_any<TAPS, NW>(st, wx, r, Y0 + r);
-				r += 1;
-			}
+	for (int q = 0; q < 10; ++q) {
+		float f[4];
+#pragma unroll
+		for (int e = 0; e < 4; ++e) {
+			const int idx = 4 * q + e;
+			f[e] = wx[idx / 10][(idx / 2) % 5][idx & 1];
 		}
-	};
-#if defined(FIXCA_EXP_STAMPS)
-	STAMP(5);                                       /* prologue */
-#endif
-	if (gen) run(std::integral_constant<int, 5>{});
-	else     run(std::integral_constant<int, T>{});
-#if defined(FIXCA_EXP_STAMPS)
-	STAMP(0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if (lane < 8) {
-		unsigned long long v = st.acc[0];
-		for (int i = 1; i < 8; ++i) v = (lane == i) ? st.acc[i] : v;
-		if (lane == 6) v = st.last - t_begin;
-		if (lane == 7) v = gen;
-		reinterpret_cast<unsigned long long *>(dst)[(size_t)tile * 8 + lane] = v;
+		cw[q * 64] = f32x4{ f[0], f[1], f[2], f[3] };
 	}
-#endif
+	if (lane == 0) {
+		RollStrip h;
+		h.U0 = U0;
+		h.tapR = (X0 + mlo[0] - U0) * 4;
+		h.tapB = (X0 + mlo[1] - U0) * 4;
+		h.gen = gen ? 1 : 0;
+		tb.strips[strip] = h;
+	}
+}
+
+/* ---- table cache + launch -------------------------------------------------------------------- */
+
+namespace {
+struct TableCache {
+	bool        valid = false;
+	int         device = -1;
+	FixcaGeom   g;                  /* y1, y2 zeroed: the tables do not depend on the row range */
+	int         oc = 0;
+	void       *mem = nullptr;
+	size_t      bytes = 0;
+	RollTables  tb;
+	hipStream_t built_on = nullptr;
+	hipEvent_t  ready = nullptr;
+};
+thread_local TableCache g_tc;
+}
+
+extern "C" void fixca_roll_release_tables(void)
+{
+	if (g_tc.mem) (void)hipFree(g_tc.mem);
+	if (g_tc.ready) (void)hipEventDestroy(g_tc.ready);
+	g_tc = TableCache();
+}
+
+static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream, RollTables *out)
+{
+	FixcaGeom key = *g;
+	key.y1 = key.y2 = 0;
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (g_tc.valid && g_tc.device == dev && g_tc.oc == pl->oc && memcmp(&g_tc.g, &key, sizeof key) == 0) {
+		if (stream != g_tc.built_on) {               /* another stream: order it after the table kernel */
+			e = hipStreamWaitEvent(stream, g_tc.ready, 0);
+			if (e != hipSuccess) return e;
+		}
+		*out = g_tc.tb;
+		return hipSuccess;
+	}
+	const size_t n_strips = (size_t)pl->nstrips;
+	const size_t off_colw = (n_strips * sizeof(RollStrip) + 255) & ~(size_t)255;
+	const size_t off_blocks = off_colw + n_strips * 10 * 64 * 16;
+	const size_t off_roww = off_blocks + (size_t)g->H * sizeof(RollBlock);
+	const size_t need = off_roww + (size_t)g->H * 8 * sizeof(float);
+	if (need > g_tc.bytes || g_tc.device != dev) {
+		/* (re)allocation happens only when the geometry grows: not inside the steady state of a
+		 * batch or a stream capture */
+		if (g_tc.mem) (void)hipFree(g_tc.mem);
+		g_tc.mem = nullptr;
+		g_tc.bytes = 0;
+		g_tc.valid = false;
+		e = hipMalloc(&g_tc.mem, need);
+		if (e != hipSuccess) return e;
+		g_tc.bytes = need;
+	}
+	if (!g_tc.ready) {
+		e = hipEventCreateWithFlags(&g_tc.ready, hipEventDisableTiming);
+		if (e != hipSuccess) return e;
+	}
+	char *base = static_cast<char *>(g_tc.mem);
+	RollTables tb;
+	tb.strips = reinterpret_cast<RollStrip *>(base);
+	tb.colw = reinterpret_cast<float *>(base + off_colw);
+	tb.blocks = reinterpret_cast<RollBlock *>(base + off_blocks);
+	tb.roww = reinterpret_cast<float *>(base + off_roww);
+	const int grid = pl->nstrips + (g->H + 63) / 64;
+	if (g->interp == 1) hipLaunchKernelGGL(k_roll_tables<2>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
+	else                hipLaunchKernelGGL(k_roll_tables<4>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
+	e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	e = hipEventRecord(g_tc.ready, stream);
+	if (e != hipSuccess) return e;
+	g_tc.valid = true;
+	g_tc.device = dev;
+	g_tc.g = key;
+	g_tc.oc = pl->oc;
+	g_tc.tb = tb;
+	g_tc.built_on = stream;
+	*out = tb;
+	return hipSuccess;
 }
 
 extern "C" hipError_t
@@ -600,14 +738,17 @@ fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 {
 	const uint8_t *s = static_cast<const uint8_t *>(d_src);
 	uint8_t *d = static_cast<uint8_t *>(d_dst);
-	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI + 64 * 32;
+	RollTables tb;
+	hipError_t e = ensure_tables(g, pl, stream, &tb);
+	if (e != hipSuccess) return e;
+	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	static bool attr_done = false;
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void *)k_roll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_roll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		attr_done = true;
 	}
-	if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
-	else                hipLaunchKernelGGL(k_roll<4>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
+	if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl, tb);
+	else                hipLaunchKernelGGL(k_roll<4>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl, tb);
 	return hipGetLastError();
 }

@@ -105,7 +105,7 @@ FIXCA_API int   fixca_dev_free(void *d_ptr);
 FIXCA_API int   fixca_copy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 FIXCA_API int   fixca_copy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
 FIXCA_API int   fixca_stream_sync(void *stream);
-FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_host's buffers */
+FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_host's buffers and the kernel tables */
 
 /* ---- timing on the launch stream (bench.py's roofline leg) -------------- */
 /*

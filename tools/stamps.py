@@ -16,6 +16,14 @@ dst = torch.empty_like(src)
 for _ in range(3):
     fixca.fix_ca_region(src, dst, W, H, 4, 1, p, 0, W, 0, H, True)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+N = 50
+e0.record()
+for _ in range(N):
+    fixca.fix_ca_region(src, dst, W, H, 4, 1, p, 0, W, 0, H, True)
+e1.record()
+torch.cuda.synchronize()
+print("event time per launch (back to back): %.2f us" % (e0.elapsed_time(e1) * 1e3 / N))
 a = dst.view(-1)[: nw * 64].cpu().numpy().view(np.uint64).reshape(nw, 8).astype(np.float64)
 names = ["outside blocks", "fetch (DMA issue + vm wait)", "LDS reads issued+landed", "filter arithmetic", "convert + store issue", "prologue", "TOTAL wave", "gen"]
 tot = a[:, 6]
@@ -23,6 +31,10 @@ print("waves", nw, " mean total cycles (memtime ticks) %.0f  min %.0f max %.0f" 
 for i in range(6):
     print("  %-30s %9.0f  %5.1f %%" % (names[i], a[:, i].mean(), 100 * a[:, i].mean() / tot.mean()))
 print("  gen-path waves: %.1f %%" % (100 * a[:, 7].mean()))
+rt = a[:, 5]
+print("  wave lifetime in 100 MHz ticks: mean %.0f (%.1f us)  -> shader clock %.2f GHz" % (rt.mean(), rt.mean() / 100, tot.mean() / rt.mean() * 0.1))
+st = a[:, 4]
+print("  wave start spread: %.1f us, (start+life) spread: %.1f us" % ((st.max() - st.min()) / 100, ((st + rt).max() - st.min()) / 100))
 g = a[:, 7] > 0
 if g.any() and (~g).any():
     print("  total fast-path waves %.0f, general-path waves %.0f" % (tot[~g].mean(), tot[g].mean()))
