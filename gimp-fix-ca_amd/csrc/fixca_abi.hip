@@ -15,6 +15,12 @@
 
 extern "C" hipError_t fixca_launch(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_copy(const void *, void *, size_t, hipStream_t);
+extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+
+/* a batch of images of one geometry: the row-rolling kernel takes up to 32 per launch, the
+ * other kernels one */
+static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
+                       hipStream_t stream, int *launches);
 
 static thread_local char g_err[512] = "";
 
@@ -126,11 +132,29 @@ extern "C" int fixca_batch_device(const void *const *d_src, void *const *d_dst, 
 	if (rc) return rc;
 	rc = fixca_make_plan(&g, flags, &pl);
 	if (rc) return rc;
-	for (int i = 0; i < n_images; ++i) {
+	for (int i = 0; i < n_images; ++i)
 		if (!d_src[i] || !d_dst[i] || d_src[i] == d_dst[i])
 			return fixca_fail(FIXCA_E_INVALID, "image %d: null or aliased pointers", i);
-		HIP_TRY(fixca_launch(d_src[i], d_dst[i], &g, &pl, (hipStream_t)stream));
+	return launch_many(d_src, d_dst, n_images, &g, &pl, (hipStream_t)stream, NULL);
+}
+
+static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
+                       hipStream_t stream, int *launches)
+{
+	int count = 0;
+	if (pl->kernel == FIXCA_K_ROLL && g->y2 > g->y1) {
+		for (int i = 0; i < n; i += 32) {
+			const int m = n - i < 32 ? n - i : 32;
+			HIP_TRY(fixca_launch_roll_batch(d_src + i, d_dst + i, m, g, pl, stream));
+			++count;
+		}
+	} else {
+		for (int i = 0; i < n; ++i) {
+			HIP_TRY(fixca_launch(d_src[i], d_dst[i], g, pl, stream));
+			++count;
+		}
 	}
+	if (launches) *launches = count;
 	return FIXCA_OK;
 }
 

@@ -8,6 +8,12 @@
 
 #include <stdint.h>
 
+/* the 256-column source window of a strip starts on a multiple of (ROLL_U0_MASK + 1) pixels:
+ * 4 pixels = 16 bytes is what the LDS-DMA and the 16-byte LDS reads need */
+#ifndef ROLL_U0_MASK
+#define ROLL_U0_MASK 3
+#endif
+
 /* one strip of `oc` output columns (16 bytes) */
 struct RollStrip {
 	int U0;             /* first column of the 256-column source window (multiple of 4)          */
@@ -30,6 +36,13 @@ struct RollTables {
 	float     *colw;    /* [nstrips][10][64 lanes][4]: a lane's 5 x 4 (red, blue) tap weights        */
 	RollBlock *blocks;  /* [H]                                                                     */
 	float     *roww;    /* [H][8]: (red, blue) vertical weights of tap 0..3                          */
+};
+
+/* the images of one launch (independent, same geometry and parameters): a kernel argument */
+#define ROLL_BATCH_MAX 32
+struct RollBatch {
+	const uint8_t *src[ROLL_BATCH_MAX];
+	uint8_t       *dst[ROLL_BATCH_MAX];
 };
 
 #endif

@@ -56,6 +56,12 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
 #define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
 #define RDEPTH      6                   /* source rows kept in flight beyond the newest row in use */
+#ifndef ROLL_LD_AUX
+#define ROLL_LD_AUX 0                   /* cache policy bits of the ring loads (2 = nt)           */
+#endif
+#ifndef ROLL_ST_AUX
+#define ROLL_ST_AUX 2                   /* cache policy bits of the row stores (2 = nt)           */
+#endif
 
 /* v_cvt_pk_u8_f32 rounds to nearest EVEN; the reference rounds half away from zero (set_pixel,
  * fix-ca.c:752): ties must go up, which a bias of 2^-13 (8 fp32 ulps at 255) does. */
@@ -149,7 +155,7 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS> &st)
 	const int slot = st.ld & st.KM;
 #if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW),
-	                                         16, st.vo_ld, st.so_ld, 0, 0);
+	                                         16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
 #endif
 	st.so_ld += st.pitch;
 }
@@ -257,7 +263,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&ac
 	 * on MI355X that store then picks up the NEXT row's bytes in the last quarter of each
 	 * 16-lane group (seen as sporadic wrong pixels).  With a constant soffset the compiler
 	 * handles the hazard. */
-	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, 2 /* nt */);
+	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
 	st.so_st += st.pitch;
 	/* stores are not counted by the fetch function's wait: see there */
 }
@@ -332,6 +338,15 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rows[t][k] = st.hist[t][k];
 
+#if defined(FIXCA_EXP_NOFILTER)                 /* timing experiment only: wrong pixels */
+#pragma unroll
+	for (int n = 0; n < NR; ++n)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			acc[n][k] = f32x2{ (float)(pr[n][k] & 0xffu), (float)((pb[n][k] >> 16) & 0xffu) } * wy[n][0];
+			rows[T - 1 + n][k] = acc[n][k];
+		}
+#else
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
 #pragma unroll
@@ -353,6 +368,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
 				acc[n][k] = __builtin_elementwise_fma(wy[n][t], rows[n + t][k], (t == 0) ? f32x2{ ROUND_BIAS, ROUND_BIAS } : acc[n][k]);
+#endif
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
@@ -373,18 +389,24 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 
 template <int TAPS>          /* 2 = LINEAR, 4 = CUBIC */
 __global__ __launch_bounds__(64) void
-k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, FixcaPlan pl, RollTables tb)
+k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	constexpr int T = TAPS;
 
+	/* One launch covers a batch of independent images: workgroups [k*nblocks, (k+1)*nblocks)
+	 * are image k's tiles (nblocks is a multiple of 8, so the XCD remap is per image).  The
+	 * dispatcher hands out workgroups in order, so image k+1's first waves start in the slots
+	 * image k's last waves leave: no fill/drain bubble per image. */
+	const int img = blockIdx.x / pl.nblocks;
 	const int lane = threadIdx.x;
-	const int tile = xcd_remap(blockIdx.x, pl.nblocks);
+	const int tile = xcd_remap(blockIdx.x - img * pl.nblocks, pl.nblocks);
 	if (tile >= pl.nwaves) return;
+	const uint8_t *__restrict__ src = imgs.src[img];
+	uint8_t *__restrict__ dst = imgs.dst[img];
 	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
 	const int W = g.W, H = g.H, oc = pl.oc;
-	int X0 = strip * oc;
-	if (X0 > W - oc) X0 = W - oc;                   /* the last strip slides left: every strip is full */
+	const int X0 = strip * oc;                      /* the last strip may be narrower: its extra lanes store nothing */
 	const int Y0 = g.y1 + chunk * pl.th;
 	const int nrows = min(pl.th, g.y2 - Y0);
 
@@ -425,7 +447,7 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	}
 
 	/* ---- per-lane tap weights: 10 coalesced 16-byte loads ---------------------------------- */
-	const int nact = oc >> 2;                        /* lanes that produce output */
+	const int nact = min(oc, W - X0) >> 2;           /* lanes that produce output */
 	f32x2 wx[4][5];
 	{
 		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
@@ -440,8 +462,10 @@ k_roll(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 #pragma unroll
 			for (int jj = 0; jj < 5; ++jj) wx[i][jj] = f32x2{ f[(i * 5 + jj) * 2], f[(i * 5 + jj) * 2 + 1] };
 	}
-	st.tap[0] = hd.tapR + 16 * lane;
-	st.tap[1] = hd.tapB + 16 * lane;
+	/* lanes past the last producing lane only serve as its DPP neighbour: they all read where
+	 * lane `nact` reads, so a narrow last strip never reads far outside its ring row */
+	st.tap[0] = hd.tapR + 16 * min(lane, nact);
+	st.tap[1] = hd.tapB + 16 * min(lane, nact);
 	st.my_idt = (uint32_t)((X0 - U0) * 4) + (uint32_t)min(lane, nact - 1) * 16;
 	/* a lane without output stores at offset `total`: past the end whether or not the range check
 	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
@@ -552,15 +576,14 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 
 	/* ---- one strip ------------------------------------------------------------------------ */
 	const int strip = blockIdx.x;
-	int X0 = strip * oc;
-	if (X0 > W - oc) X0 = W - oc;
+	const int X0 = strip * oc;
 	int lo = X0;
 #pragma unroll
 	for (int c = 0; c < 2; ++c)
 		lo = min(lo, rclampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1));
-	const int U0 = min(lo & ~3, W - FIXCA_WAVE_COLS);
+	const int U0 = min(lo & ~ROLL_U0_MASK, W - FIXCA_WAVE_COLS);
 
-	const int nact = oc >> 2;                        /* lanes that produce output */
+	const int nact = min(oc, W - X0) >> 2;           /* lanes that produce output */
 	const bool active = lane < nact;
 	const int xl = X0 + 4 * min(lane, nact - 1);     /* first output column of this lane */
 
@@ -733,11 +756,17 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	return hipSuccess;
 }
 
+/* n_images images (1 .. ROLL_BATCH_MAX) in one launch */
 extern "C" hipError_t
-fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+fixca_launch_roll_batch(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g,
+                        const FixcaPlan *pl, hipStream_t stream)
 {
-	const uint8_t *s = static_cast<const uint8_t *>(d_src);
-	uint8_t *d = static_cast<uint8_t *>(d_dst);
+	if (n_images < 1 || n_images > ROLL_BATCH_MAX) return hipErrorInvalidValue;
+	RollBatch imgs;
+	for (int i = 0; i < ROLL_BATCH_MAX; ++i) {
+		imgs.src[i] = static_cast<const uint8_t *>(d_src[i < n_images ? i : 0]);
+		imgs.dst[i] = static_cast<uint8_t *>(d_dst[i < n_images ? i : 0]);
+	}
 	RollTables tb;
 	hipError_t e = ensure_tables(g, pl, stream, &tb);
 	if (e != hipSuccess) return e;
@@ -748,7 +777,14 @@ fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 		(void)hipFuncSetAttribute((const void *)k_roll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		attr_done = true;
 	}
-	if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl, tb);
-	else                hipLaunchKernelGGL(k_roll<4>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl, tb);
+	const dim3 grid((unsigned)pl->nblocks * (unsigned)n_images);
+	if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	else                hipLaunchKernelGGL(k_roll<4>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
 	return hipGetLastError();
+}
+
+extern "C" hipError_t
+fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+{
+	return fixca_launch_roll_batch(&d_src, &d_dst, 1, g, pl, stream);
 }

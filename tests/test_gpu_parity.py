@@ -215,6 +215,22 @@ def test_batch_entry(torch_cuda):
         assert mx <= TOL_LSB
 
 
+def test_batch_entry_more_images_than_one_launch_takes(torch_cuda):
+    """the row-rolling kernel takes 32 images per launch: 70 images = 3 launches"""
+    torch = torch_cuda
+    p = fixca.make_params(blue=0.5, red=-0.4, lens_x=300, lens_y=20, interpolation=2, x_blue=1.25, y_red=-0.5)
+    assert fixca.plan(512, 40, 4, 1, p)[0] == 6
+    base = synth.noise_image(77, 512, 40, 4)
+    imgs = [np.roll(base, 3 * i, axis=1) for i in range(70)]
+    srcs = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in imgs]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    fixca.fix_ca_batch(srcs, dsts, 512, 40, 4, 1, p)
+    torch.cuda.synchronize()
+    for i in (0, 1, 31, 32, 33, 63, 64, 69):
+        mx, _ = diff_stats(dsts[i].cpu().numpy(), oracle_run(np.ascontiguousarray(imgs[i]), p))
+        assert mx <= TOL_LSB, i
+
+
 @pytest.mark.parametrize("case", [c for c in VEC["full"] if c["width"] == 6000], ids=lambda c: c["name"])
 def test_full_size_configs(torch_cuda, case):
     """BASELINE.json configs at full size: the fp64 kernel must reproduce the reference's

@@ -28,7 +28,7 @@ def traffic_json(d, kernel_prefix, out_path):
                 vals[name] = statistics.mean(v)
     if len(vals) == 2:
         rd, wr = vals["FETCH_SIZE"] * 2 * 1024, vals["WRITE_SIZE"] * 1024
-        json.dump({"kernel": kernel_prefix, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+        json.dump({"kernel": kernel_prefix, "images_per_launch": int(os.environ.get("FIXCA_PROF_IMAGES", "1")), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                    "bytes_per_launch": round(rd + wr),
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KB -> bytes; FETCH_SIZE x2 (gfx950)"},
                   open(out_path, "w"), indent=1)
