@@ -3,10 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
-One step = one pass of the hot path (fixca_batch_device -> the row-scan kernel)
-over a batch of B independent 6000x4000 RGBA8 synthetic images already resident in
-HBM (B src + B dst buffers; B >= 4 so the working set exceeds the 256 MB Infinity
-Cache).  Workload = BASELINE.json config "lateral cubic + off-centre lens
+One step = one pass of the hot path (fixca_batch_device -> the row-rolling kernel,
+which takes up to 32 images of a batch per launch) over a batch of B independent
+6000x4000 RGBA8 synthetic images already resident in HBM (B src + B dst buffers;
+B >= 4 so the working set exceeds the 256 MB Infinity Cache).  Workload = BASELINE.json config "lateral cubic + off-centre lens
 (658,1280)", blue +2 / red -2.  With N > 1 (launched by torch.distributed.run, one
 rank per GPU) every rank owns B images of a global batch of N*B (image i -> rank
 i mod N), rank 0 broadcasts the parameter block over RCCL, and `value` is the
@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras that launch other kernels or single images (copy yardstick, "
+                         "host-entry run); tools/profile.sh uses it so that rocprof's per-kernel average is over "
+                         "the timed launches only")
     args = ap.parse_args()
 
     import torch
@@ -141,16 +145,17 @@ def main():
                                           "samples": int(diff.numel())}
         ok = extra["parity_vs_fp64_kernel"]["max_abs_diff"] <= 1
         del exact, diff
-        copy_ms = fixca.time_copy(srcs, dsts, 10 * B, W * H * C)
-        extra["copy_kernel_GBs"] = round(2 * W * H * C / (copy_ms * 1e-3) / 1e9, 1)
-        import numpy as np
-        hsrc = srcs[0].cpu().numpy()
-        hdst = np.empty_like(hsrc)
-        fixca.fix_ca_region(hsrc, hdst, W, H, C, 1, params, 0, W, 0, H, True)     # warm (allocs, context)
-        t = time.perf_counter()
-        fixca.fix_ca_region(hsrc, hdst, W, H, C, 1, params, 0, W, 0, H, True)
-        extra["host_entry_pcie_inclusive_mpix_s"] = round(W * H / (time.perf_counter() - t) / 1e6, 1)
-        fixca.lib.fixca_release_cache()
+        if not args.no_extras:
+            copy_ms = fixca.time_copy(srcs, dsts, 10 * B, W * H * C)
+            extra["copy_kernel_GBs"] = round(2 * W * H * C / (copy_ms * 1e-3) / 1e9, 1)
+            import numpy as np
+            hsrc = srcs[0].cpu().numpy()
+            hdst = np.empty_like(hsrc)
+            fixca.fix_ca_region(hsrc, hdst, W, H, C, 1, params, 0, W, 0, H, True)     # warm (allocs, context)
+            t = time.perf_counter()
+            fixca.fix_ca_region(hsrc, hdst, W, H, C, 1, params, 0, W, 0, H, True)
+            extra["host_entry_pcie_inclusive_mpix_s"] = round(W * H / (time.perf_counter() - t) / 1e6, 1)
+            fixca.lib.fixca_release_cache()
     ok = fdist.all_ranks_ok(ok, device=dev)
 
     if rank == 0:

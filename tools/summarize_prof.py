@@ -22,10 +22,12 @@ def traffic_json(d, kernel_prefix, out_path):
     vals = {}
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(os.path.join(d, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True):
-            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                 if short(r["Kernel_Name"]).startswith(kernel_prefix) and r["Counter_Name"] == name]
-            if v:
-                vals[name] = statistics.mean(v)
+            rows = [r for r in csv.DictReader(open(f))
+                    if short(r["Kernel_Name"]).startswith(kernel_prefix) and r["Counter_Name"] == name]
+            if rows:
+                # the batched launches only (largest grid): the same command also makes single-image calls
+                gmax = max(int(r["Grid_Size"]) for r in rows)
+                vals[name] = statistics.mean(float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == gmax)
     if len(vals) == 2:
         rd, wr = vals["FETCH_SIZE"] * 2 * 1024, vals["WRITE_SIZE"] * 1024
         json.dump({"kernel": kernel_prefix, "images_per_launch": int(os.environ.get("FIXCA_PROF_IMAGES", "1")), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
