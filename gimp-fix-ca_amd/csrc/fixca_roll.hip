@@ -677,7 +677,10 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 /* ---- table cache + launch -------------------------------------------------------------------- */
 
 namespace {
-struct TableCache {
+/* Tables live in device memory and are read by kernels that may still be running when the
+ * next call arrives, so a geometry keeps its own buffer: a small per-thread cache of entries.
+ * An entry is rebuilt (another geometry evicts it) only after the device has gone idle. */
+struct TableEntry {
 	bool        valid = false;
 	int         device = -1;
 	FixcaGeom   g;                  /* y1, y2 zeroed: the tables do not depend on the row range */
@@ -687,15 +690,20 @@ struct TableCache {
 	RollTables  tb;
 	hipStream_t built_on = nullptr;
 	hipEvent_t  ready = nullptr;
+	unsigned long long used = 0;
 };
-thread_local TableCache g_tc;
+constexpr int TABLE_ENTRIES = 4;
+thread_local TableEntry g_tc[TABLE_ENTRIES];
+thread_local unsigned long long g_tick = 0;
 }
 
 extern "C" void fixca_roll_release_tables(void)
 {
-	if (g_tc.mem) (void)hipFree(g_tc.mem);
-	if (g_tc.ready) (void)hipEventDestroy(g_tc.ready);
-	g_tc = TableCache();
+	for (TableEntry &e : g_tc) {
+		if (e.mem) (void)hipFree(e.mem);
+		if (e.ready) (void)hipEventDestroy(e.ready);
+		e = TableEntry();
+	}
 }
 
 static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream, RollTables *out)
@@ -705,35 +713,52 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
-	if (g_tc.valid && g_tc.device == dev && g_tc.oc == pl->oc && memcmp(&g_tc.g, &key, sizeof key) == 0) {
-		if (stream != g_tc.built_on) {               /* another stream: order it after the table kernel */
-			e = hipStreamWaitEvent(stream, g_tc.ready, 0);
-			if (e != hipSuccess) return e;
+	for (TableEntry &t : g_tc) {
+		if (t.valid && t.device == dev && t.oc == pl->oc && memcmp(&t.g, &key, sizeof key) == 0) {
+			if (stream != t.built_on) {              /* another stream: order it after the table kernel */
+				e = hipStreamWaitEvent(stream, t.ready, 0);
+				if (e != hipSuccess) return e;
+			}
+			t.used = ++g_tick;
+			*out = t.tb;
+			return hipSuccess;
 		}
-		*out = g_tc.tb;
-		return hipSuccess;
+	}
+	TableEntry *slot = nullptr;                      /* a free entry, else the least recently used */
+	for (TableEntry &t : g_tc)
+		if (!t.valid) { slot = &t; break; }
+	if (!slot) {
+		slot = &g_tc[0];
+		for (TableEntry &t : g_tc)
+			if (t.used < slot->used) slot = &t;
+	}
+	TableEntry &t = *slot;
+	if (t.valid) {
+		/* eviction: kernels on any stream may still be reading this entry's tables */
+		e = hipDeviceSynchronize();
+		if (e != hipSuccess) return e;
+		t.valid = false;
 	}
 	const size_t n_strips = (size_t)pl->nstrips;
 	const size_t off_colw = (n_strips * sizeof(RollStrip) + 255) & ~(size_t)255;
 	const size_t off_blocks = off_colw + n_strips * 10 * 64 * 16;
 	const size_t off_roww = off_blocks + (size_t)g->H * sizeof(RollBlock);
 	const size_t need = off_roww + (size_t)g->H * 8 * sizeof(float);
-	if (need > g_tc.bytes || g_tc.device != dev) {
-		/* (re)allocation happens only when the geometry grows: not inside the steady state of a
-		 * batch or a stream capture */
-		if (g_tc.mem) (void)hipFree(g_tc.mem);
-		g_tc.mem = nullptr;
-		g_tc.bytes = 0;
-		g_tc.valid = false;
-		e = hipMalloc(&g_tc.mem, need);
+	if (need > t.bytes || t.device != dev) {
+		/* (re)allocation happens only for a new or larger geometry: not inside the steady state
+		 * of a batch or a stream capture */
+		if (t.mem) (void)hipFree(t.mem);
+		t.mem = nullptr;
+		t.bytes = 0;
+		e = hipMalloc(&t.mem, need);
 		if (e != hipSuccess) return e;
-		g_tc.bytes = need;
+		t.bytes = need;
 	}
-	if (!g_tc.ready) {
-		e = hipEventCreateWithFlags(&g_tc.ready, hipEventDisableTiming);
+	if (!t.ready) {
+		e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
 		if (e != hipSuccess) return e;
 	}
-	char *base = static_cast<char *>(g_tc.mem);
+	char *base = static_cast<char *>(t.mem);
 	RollTables tb;
 	tb.strips = reinterpret_cast<RollStrip *>(base);
 	tb.colw = reinterpret_cast<float *>(base + off_colw);
@@ -744,14 +769,15 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	else                hipLaunchKernelGGL(k_roll_tables<4>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	e = hipEventRecord(g_tc.ready, stream);
+	e = hipEventRecord(t.ready, stream);
 	if (e != hipSuccess) return e;
-	g_tc.valid = true;
-	g_tc.device = dev;
-	g_tc.g = key;
-	g_tc.oc = pl->oc;
-	g_tc.tb = tb;
-	g_tc.built_on = stream;
+	t.valid = true;
+	t.device = dev;
+	t.g = key;
+	t.oc = pl->oc;
+	t.tb = tb;
+	t.built_on = stream;
+	t.used = ++g_tick;
 	*out = tb;
 	return hipSuccess;
 }

@@ -215,6 +215,35 @@ def test_batch_entry(torch_cuda):
         assert mx <= TOL_LSB
 
 
+def test_table_cache_across_geometries_and_streams(torch_cuda):
+    """k_roll's tables are built once per geometry/parameters on the launching stream and reused:
+    alternate two geometries and two streams and check every result."""
+    torch = torch_cuda
+    cases = [(512, 90, dict(blue=0.5, red=-0.4, lens_x=300, lens_y=20, interpolation=2, x_blue=1.25)),
+             (768, 70, dict(blue=-0.6, red=0.8, lens_x=100, lens_y=60, interpolation=1, y_red=2.5))]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    data = []
+    for w, h, kw in cases:
+        img = synth.noise_image(w + h, w, h, 4)
+        p = fixca.make_params(**kw)
+        assert fixca.plan(w, h, 4, 1, p)[0] == 6
+        data.append((img, p, oracle_run(img, p), torch.from_numpy(img).cuda()))
+    torch.cuda.synchronize()
+    outs = []
+    for it in range(8):
+        img, p, ref, src = data[it % 2]
+        h, w, _ = img.shape
+        st = streams[(it // 2) % 2]
+        dst = torch.empty_like(src)
+        with torch.cuda.stream(st):
+            fixca.fix_ca_region(src, dst, w, h, 4, 1, p, 0, w, 0, h, True)
+        outs.append((dst, ref))
+    torch.cuda.synchronize()
+    for dst, ref in outs:
+        mx, _ = diff_stats(dst.cpu().numpy(), ref)
+        assert mx <= TOL_LSB
+
+
 def test_batch_entry_more_images_than_one_launch_takes(torch_cuda):
     """the row-rolling kernel takes 32 images per launch: 70 images = 3 launches"""
     torch = torch_cuda

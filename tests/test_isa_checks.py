@@ -1,0 +1,72 @@
+"""CPU checks on the generated gfx950 code of the row-rolling kernel (hipcc cross-compiles
+without a GPU).  Two properties of fixca_roll.hip rest on what the compiler emits:
+
+  * the DPP byte->float conversions are hand-written asm, which the compiler's hazard
+    recognizer does not see: a VALU write of a register within two instructions before a DPP
+    read of it needs wait states the asm does not carry.  Their sources must come from LDS loads.
+  * the 16-byte row stores must not carry the row offset in the SGPR soffset operand (hipcc emits
+    no wait state for that form and on MI355X the store then picks up the next row's bytes).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gimp-fix-ca_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def roll_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC) and not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "roll.s"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(CSRC, "fixca_roll.hip")], stderr=subprocess.DEVNULL)
+    lines = [l for l in out.read_text().split("\n")
+             if l.startswith("\t") and not l.strip().startswith((";", "."))]
+    return lines
+
+
+def _dst_regs(line):
+    t = line.strip().replace(",", " ").split()
+    if len(t) < 2:
+        return set()
+    m = re.match(r"v\[(\d+):(\d+)\]$", t[1])
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", t[1])
+    return {int(m.group(1))} if m else set()
+
+
+def test_dpp_sources_are_not_fresh_valu_results(roll_asm):
+    ndpp = 0
+    for i, l in enumerate(roll_asm):
+        if "_dpp" not in l:
+            continue
+        ndpp += 1
+        src = int(re.match(r"v(\d+)$", l.strip().replace(",", " ").split()[2]).group(1))
+        for back in (1, 2):
+            p = roll_asm[i - back].strip()
+            assert not (p.startswith("v_") and src in _dst_regs(p)), "DPP hazard: %s -> %s" % (p, l.strip())
+    assert ndpp >= 16            # the conversions are there at all
+
+
+def test_row_stores_keep_soffset_constant(roll_asm):
+    stores = [l.strip() for l in roll_asm if l.strip().startswith("buffer_store_dwordx4")]
+    assert stores
+    for s in stores:
+        # buffer_store_dwordx4 vdata, voffset, srsrc, soffset offen ...: soffset must be the literal 0
+        ops = [o.strip() for o in s.split(None, 1)[1].split(",")]
+        assert ops[3].split()[0] == "0", s
+
+
+def test_ring_loads_are_lds_dma_and_scalar_tables(roll_asm):
+    text = "\n".join(roll_asm)
+    assert re.search(r"buffer_load_dwordx4 .* lds", text)          # LDS-DMA ring fill
+    assert "s_load_dwordx" in text                                 # block descriptors / weights via SMEM
+    assert "v_readlane_b32" not in text                            # 3x the cost of a VALU op: tables replaced them
