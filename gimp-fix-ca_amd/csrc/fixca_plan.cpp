@@ -237,6 +237,10 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int *last)
 {
 	const int W = g->W;
+	if (taps == 1) {                                    /* NONE: the rounded source column, weight 1 */
+		*first = *last = h_map_int(x, g->xc, W, g->s[c], g->xs[c]);
+		return;
+	}
 	const double xd = h_map_dbl(x, g->xc, W, g->s[c], g->xs[c]);
 	const int x0 = (int)floor(xd);
 	if (xd - (double)x0 == 0.0) {
@@ -266,7 +270,8 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 		const int xe = X0 + oc < W ? X0 + oc : W;
 		int lo = X0, hi = xe - 1, m[2];
 		for (int c = 0; c < 2; ++c) {
-			int a = clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1);
+			int a = taps == 1 ? h_map_int(X0, g->xc, W, g->s[c], g->xs[c])
+			                  : clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1);
 			if (a < lo) lo = a;
 		}
 		for (int c = 0; c < 2; ++c) {
@@ -296,10 +301,10 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 
 static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 {
-	if (g->bpp != 4 || (g->W & 3) || g->W < FIXCA_WAVE_COLS || g->interp == 0) return false;
+	if (g->bpp != 4 || (g->W & 3) || g->W < FIXCA_WAVE_COLS) return false;
 	if ((long long)g->W * g->H * 4 > (1LL << 31)) return false;            /* 32-bit buffer offsets, see k_roll */
-	const int taps = (g->interp == 1) ? 2 : 4;
-	const int span = scan_row_span(g, taps);
+	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
+	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* a block of 4 output rows keeps span + 3 rows alive; leave >= 2 slots for rows in flight */
 	int ring = env_int("FIXCA_RING", 0, 0, 32);
 	if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : 32;

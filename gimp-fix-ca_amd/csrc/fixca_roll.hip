@@ -145,7 +145,7 @@ struct RollState {
 	uint32_t so_st;             /* byte offset of the next output row                           */
 	uint32_t pitch;
 	/* the newest T-1 horizontally filtered rows, (red, blue) of my 4 output columns */
-	f32x2    hist[T - 1][4];
+	f32x2    hist[T > 1 ? T - 1 : 1][4];             /* unused when T == 1 */
 };
 
 template <int TAPS>
@@ -387,7 +387,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 	STAMP(4);                                       /* conversions + stores */
 }
 
-template <int TAPS>          /* 2 = LINEAR, 4 = CUBIC */
+template <int TAPS>          /* 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
 __global__ __launch_bounds__(64) void
 k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 {
@@ -495,7 +495,7 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	STAMP(5);                                       /* prologue */
 #endif
 	if (hd.gen) run(std::integral_constant<int, 5>{});
-	else        run(std::integral_constant<int, T>{});
+	else        run(std::integral_constant<int, (T == 1) ? 2 : T>{});
 #if defined(FIXCA_EXP_STAMPS)
 	STAMP(0);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -530,10 +530,15 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 		const int y = ((int)blockIdx.x - pl.nstrips) * 64 + lane;
 		if (y >= H) return;
 		auto row_of = [&](int yy, int c, int &rb, float *wy) {
-			double yd = map_dbl(yy, g.yc, H, g.s[c], g.ys[c]);
-			int y0 = (int)floor(yd);
-			if (wy) tap_weights_f32<T>((float)(yd - (double)y0), wy);
-			rb = y0 - BACK;
+			if constexpr (T == 1) {                      /* NONE: the rounded source row (fix-ca.c:799-809), weight 1 */
+				rb = map_int(yy, g.yc, H, g.s[c], g.ys[c]);
+				if (wy) wy[0] = 1.0f;
+			} else {
+				double yd = map_dbl(yy, g.yc, H, g.s[c], g.ys[c]);
+				int y0 = (int)floor(yd);
+				if (wy) tap_weights_f32<T>((float)(yd - (double)y0), wy);
+				rb = y0 - BACK;
+			}
 		};
 		auto describe = [&](int yy, int &rbR, int &rbB, int &keep, int &need, bool &reg, float (*wy)[T]) {
 			int rb[2];
@@ -579,8 +584,10 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 	const int X0 = strip * oc;
 	int lo = X0;
 #pragma unroll
-	for (int c = 0; c < 2; ++c)
-		lo = min(lo, rclampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1));
+	for (int c = 0; c < 2; ++c) {
+		if constexpr (T == 1) lo = min(lo, map_int(X0, g.xc, W, g.s[c], g.xs[c]));
+		else lo = min(lo, rclampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1));
+	}
 	const int U0 = min(lo & ~ROLL_U0_MASK, W - FIXCA_WAVE_COLS);
 
 	const int nact = min(oc, W - X0) >> 2;           /* lanes that produce output */
@@ -596,30 +603,38 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			const int x = xl + i;
-			const double xd = map_dbl(x, g.xc, W, g.s[c], g.xs[c]);
-			const int x0 = (int)floor(xd);
-			const double fx = xd - (double)x0;
-			tap_weights_f32<T>((float)fx, wt[c][i]);
-			if constexpr (T == 4) {
-				col[c][i][0] = max(x0 - 1, 0);                      /* fix-ca.c:1270-1298 */
-				col[c][i][1] = x0;
-				col[c][i][2] = min(x0 + 1, W - 1);
-				col[c][i][3] = min(col[c][i][2] + 1, W - 1);
-			} else {
-				col[c][i][0] = x0;                                  /* fix-ca.c:1170-1177 */
-				col[c][i][1] = min(x0 + 1, W - 1);
-			}
-			/* A coordinate that sits exactly on a column (every coordinate clamped to the image
-			 * edge does) has all its weight on that column; its other taps, which may lie far
-			 * from the rest of the strip's, do not count.  Host and device take this decision on
-			 * the fp64 fraction, where they agree bit for bit. */
-			constexpr int CT = (T == 4) ? 1 : 0;                    /* the tap with weight 1 at fraction 0 */
-			if (fx != 0.0) {
+			if constexpr (T == 1) {
+				/* NONE: one "tap" of weight 1 on the rounded source column (fix-ca.c:799-809);
+				 * the 0/1 weights make the fp32 filter below an exact byte gather */
+				col[c][i][0] = map_int(x, g.xc, W, g.s[c], g.xs[c]);
+				wt[c][i][0] = 1.0f;
 				mlo[c] = min(mlo[c], col[c][i][0] - x);
 			} else {
-				mlo[c] = min(mlo[c], col[c][i][CT] - x);
+				const double xd = map_dbl(x, g.xc, W, g.s[c], g.xs[c]);
+				const int x0 = (int)floor(xd);
+				const double fx = xd - (double)x0;
+				tap_weights_f32<T>((float)fx, wt[c][i]);
+				if constexpr (T == 4) {
+					col[c][i][0] = max(x0 - 1, 0);                      /* fix-ca.c:1270-1298 */
+					col[c][i][1] = x0;
+					col[c][i][2] = min(x0 + 1, W - 1);
+					col[c][i][3] = min(col[c][i][2] + 1, W - 1);
+				} else {
+					col[c][i][0] = x0;                                  /* fix-ca.c:1170-1177 */
+					col[c][i][T - 1] = min(x0 + 1, W - 1);
+				}
+				/* A coordinate that sits exactly on a column (every coordinate clamped to the image
+				 * edge does) has all its weight on that column; its other taps, which may lie far
+				 * from the rest of the strip's, do not count.  Host and device take this decision on
+				 * the fp64 fraction, where they agree bit for bit. */
+				constexpr int CT = (T == 4) ? 1 : 0;                    /* the tap with weight 1 at fraction 0 */
+				if (fx != 0.0) {
+					mlo[c] = min(mlo[c], col[c][i][0] - x);
+				} else {
+					mlo[c] = min(mlo[c], col[c][i][CT] - x);
 #pragma unroll
-				for (int t = 0; t < T; ++t) wt[c][i][t] = (t == CT) ? 1.0f : 0.0f;
+					for (int t = 0; t < T; ++t) wt[c][i][t] = (t == CT) ? 1.0f : 0.0f;
+				}
 			}
 		}
 	/* strip minimum: butterfly over the wave (inactive lanes carry copies of lane nact-1) */
@@ -647,7 +662,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 					a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
 			wx[i][jj][0] = a[0];
 			wx[i][jj][1] = a[1];
-			if (jj >= T) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
+			if (jj >= ((T == 1) ? 2 : T)) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
 		}
 	gen = __any(gen && active) != 0;
 
@@ -765,8 +780,9 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	tb.blocks = reinterpret_cast<RollBlock *>(base + off_blocks);
 	tb.roww = reinterpret_cast<float *>(base + off_roww);
 	const int grid = pl->nstrips + (g->H + 63) / 64;
-	if (g->interp == 1) hipLaunchKernelGGL(k_roll_tables<2>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
-	else                hipLaunchKernelGGL(k_roll_tables<4>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
+	if (g->interp == 0)      hipLaunchKernelGGL(k_roll_tables<1>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
+	else if (g->interp == 1) hipLaunchKernelGGL(k_roll_tables<2>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
+	else                     hipLaunchKernelGGL(k_roll_tables<4>, dim3(grid), dim3(64), 0, stream, *g, *pl, tb);
 	e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	e = hipEventRecord(t.ready, stream);
@@ -799,13 +815,15 @@ fixca_launch_roll_batch(const void *const *d_src, void *const *d_dst, int n_imag
 	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	static bool attr_done = false;
 	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void *)k_roll<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_roll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_roll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		attr_done = true;
 	}
 	const dim3 grid((unsigned)pl->nblocks * (unsigned)n_images);
-	if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-	else                hipLaunchKernelGGL(k_roll<4>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	if (g->interp == 0)      hipLaunchKernelGGL(k_roll<1>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	else if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	else                     hipLaunchKernelGGL(k_roll<4>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
 	return hipGetLastError();
 }
 

@@ -86,7 +86,7 @@ def test_planner_choices():
     k, desc = fixca.plan(6000, 4000, 4, 1, lin)
     assert k == 6 and "roll linear" in desc
     k, desc = fixca.plan(6000, 4000, 4, 1, fixca.make_params(blue=1.5, red=-1.5, lens_x=3000, lens_y=2000))
-    assert k == 4 and "scan none" in desc
+    assert k == 6 and "roll none" in desc                               # NONE runs as an exact 1-tap filter
     k, desc = fixca.plan(6000, 4000, 3, 1, cub)                         # RGB: register-window kernel
     assert k == 3 and "fast-interp cubic" in desc and "oc=252" in desc
     assert fixca.plan(6000, 4000, 3, 1, fixca.make_params(blue=1.5, red=-1.5, lens_x=3000, lens_y=2000))[0] == 2

@@ -357,7 +357,7 @@ def test_kernel_variants_agree_with_oracle(torch_cuda, monkeypatch, variant, sha
         kid, desc = fixca.plan(w, h, 4, 1, p, kernel=fixca.KERNEL_FAST)
         if variant.startswith("roll"):
             assert kid in (3, 4, 6), desc
-            if interp and pi in (0, 2) and w >= 2048:
+            if pi in (0, 2) and w >= 2048:
                 assert kid == 6, desc                       # mild scales: the rolling kernel must take these
         elif variant.startswith("scanw"):
             assert kid in (3, 5), desc
