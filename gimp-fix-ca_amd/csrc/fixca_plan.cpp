@@ -306,9 +306,12 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* a block of 4 output rows keeps span + 3 rows alive; leave >= 2 slots for rows in flight */
-	int ring = env_int("FIXCA_RING", 0, 0, 32);
-	if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : 32;
-	if ((ring & (ring - 1)) || span + 5 > ring) return false;
+	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that
+	 * fits (row mod 16 is one instruction); otherwise as small as 6 rows in flight allow, because
+	 * every KB of ring is a wave less per CU (160 KB of LDS) */
+	int ring = env_int("FIXCA_RING", 0, 0, 64);
+	if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : span + 9;
+	if (ring > 64 || span + 5 > ring) return false;
 	/* Strip width: a multiple of 16 pixels makes every row store start and end on a 64-byte
 	 * boundary (no memory line is shared by two waves' stores; measured 6 % faster than the
 	 * widest width that fits, 248); other widths only if no such width fits. */

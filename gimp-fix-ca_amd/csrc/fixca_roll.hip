@@ -44,6 +44,7 @@
  */
 #include "fixca_device.h"
 #include "fixca_roll.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -122,7 +123,7 @@ __device__ __forceinline__ float next_lane_ubyte2(uint32_t v)
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int TAPS>
+template <int TAPS, bool P2>          /* P2: the ring has a power-of-two number of rows */
 struct RollState {
 #if defined(FIXCA_EXP_STAMPS)
 	unsigned long long last, acc[8];
@@ -132,7 +133,8 @@ struct RollState {
 	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
 	/* ring */
 	uint8_t *ring;
-	int      KM, H;
+	int      KM, H;             /* KM = K - 1 (a mask when K is a power of two)                 */
+	uint32_t kmagic;            /* ceil(2^32 / K): row mod K = row - K * mulhi(row, kmagic), row < 2^24 */
 	int      ld;                /* highest source row issued                                   */
 	int      lastneed;          /* highest source row this wave ever needs                     */
 	/* global memory goes through buffer descriptors: the per-lane part of an address is a
@@ -148,11 +150,19 @@ struct RollState {
 	f32x2    hist[T > 1 ? T - 1 : 1][4];             /* unused when T == 1 */
 };
 
-template <int TAPS>
-__device__ __forceinline__ void roll_issue(RollState<TAPS> &st)
+/* ring slot of source row `row` (row >= 0): row mod K */
+template <int TAPS, bool P2>
+__device__ __forceinline__ int roll_slot(const RollState<TAPS, P2> &st, int row)
+{
+	if constexpr (P2) return row & st.KM;
+	else return row - (st.KM + 1) * (int)__umulhi((uint32_t)row, st.kmagic);
+}
+
+template <int TAPS, bool P2>
+__device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
 {
 	++st.ld;
-	const int slot = st.ld & st.KM;
+	const int slot = roll_slot(st, st.ld);
 #if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW),
 	                                         16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
@@ -169,8 +179,8 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS> &st)
  * younger than the one needed, and "at most ld - need operations outstanding" implies "at most
  * ld - need loads outstanding", which implies the needed row is in LDS.  Stores in flight make
  * the wait stricter, never wrong. */
-template <int TAPS>
-__device__ __forceinline__ void roll_fetch(RollState<TAPS> &st, int keep, int need)
+template <int TAPS, bool P2>
+__device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, int need)
 {
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) roll_issue(st);
@@ -186,23 +196,23 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS> &st, int keep, int ne
 }
 
 /* 16 bytes of ring row `row` at a 16-byte aligned offset */
-template <int TAPS>
-__device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS> &st, int row, uint32_t off)
+template <int TAPS, bool P2>
+__device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int row, uint32_t off)
 {
-	return *reinterpret_cast<const u32x4 *>(st.ring + (row & st.KM) * RING_ROW + off);
+	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 }
 
 /* 16 bytes of ring row `row` at a pixel (4-byte) aligned offset.  A ds_read_b128 from an address
  * that is not 16-byte aligned returns the right data on gfx950 but takes ~65 LDS cycles instead
  * of 4 (measured), so the access is left to the compiler as 4-byte aligned: two ds_read2_b32. */
 struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
-template <int TAPS>
-__device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS> &st, int row, int off)
+template <int TAPS, bool P2>
+__device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2> &st, int row, int off)
 {
 #if defined(FIXCA_EXP_ALIGNED)                  /* timing experiment only: wrong pixels */
-	return *reinterpret_cast<const u32x4 *>(st.ring + (row & st.KM) * RING_ROW + (off & ~15));
+	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~15));
 #else
-	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + (row & st.KM) * RING_ROW + off);
+	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, v.d };
 #endif
 }
@@ -221,8 +231,8 @@ __device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, f32x2
 
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
  * h[i] = sum_t wx[i][t] * px8[i + t] for my 4 output columns */
-template <int TAPS, int NW>
-__device__ __forceinline__ void roll_hrow(const RollState<TAPS> &st, const f32x2 (&wx)[4][5],
+template <int TAPS, bool P2, int NW>
+__device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5],
                                           int rowR, int rowB, f32x2 (&h)[4])
 {
 	const u32x4 pr = roll_ring_win(st, rowR, st.tap[0]);
@@ -248,8 +258,8 @@ __device__ __forceinline__ void roll_wy(cfloat_p roww, int y, f32x2 (&wy)[TAPS])
 }
 
 /* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
-template <int TAPS>
-__device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&acc)[4], const u32x4 &idt)
+template <int TAPS, bool P2>
+__device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 (&acc)[4], const u32x4 &idt)
 {
 	u32x4 out;
 #pragma unroll
@@ -270,8 +280,8 @@ __device__ __forceinline__ void roll_store(RollState<TAPS> &st, const f32x2 (&ac
 
 /* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
  * window touches the top or bottom edge: edge rows replicate, fix-ca.c:1218-1256) */
-template <int TAPS, int NW>
-__device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
+template <int TAPS, bool P2, int NW>
+__device__ __forceinline__ void roll_row_any(RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                              cfloat_p roww, int y)
 {
 	constexpr int T = TAPS;
@@ -280,7 +290,7 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&
 	f32x2 rows[T][4];
 #pragma unroll
 	for (int t = 0; t < T; ++t)
-		roll_hrow<TAPS, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
+		roll_hrow<TAPS, P2, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
 	f32x2 v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
@@ -301,8 +311,8 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS> &st, const f32x2 (&
  * All ring reads of the rows are issued together; the filter arithmetic is written tap-major
  * (for each tap, all rows and outputs) so that consecutive instructions belong to different
  * accumulation chains. */
-template <int TAPS, int NW, int NR>
-__device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
+template <int TAPS, bool P2, int NW, int NR>
+__device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                            const RollBlock &bn, cfloat_p roww, int y)
 {
 	constexpr int T = TAPS;
@@ -387,7 +397,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS> &st, const f32x2 (&wx
 	STAMP(4);                                       /* conversions + stores */
 }
 
-template <int TAPS>          /* 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
+template <int TAPS, bool P2>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
 __global__ __launch_bounds__(64) void
 k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 {
@@ -410,14 +420,15 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	const int Y0 = g.y1 + chunk * pl.th;
 	const int nrows = min(pl.th, g.y2 - Y0);
 
-	RollState<TAPS> st;
+	RollState<TAPS, P2> st;
 #if defined(FIXCA_EXP_STAMPS)
 	st.last = __builtin_amdgcn_s_memtime();
 	const unsigned long long t_begin = st.last;
 	const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 	for (int i = 0; i < 8; ++i) st.acc[i] = 0;
 #endif
-	st.KM = pl.ring - 1;                            /* ring rows: power of two */
+	st.KM = pl.ring - 1;
+	st.kmagic = (uint32_t)((0x100000000ull + (unsigned)pl.ring - 1) / (unsigned)pl.ring);
 	st.H = H;
 	st.pitch = (uint32_t)W * 4u;
 	st.ring = lds + RING_PAD_LO;
@@ -484,9 +495,9 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 			 * whole block to come back */
 			RollBlock bn = b;
 			if (r + step < nrows) bn = load_block(blocks, y + step);
-			if (four)     roll_block<TAPS, NW, 4>(st, wx, b, bn, roww, y);
-			else if (one) roll_block<TAPS, NW, 1>(st, wx, b, bn, roww, y);
-			else          roll_row_any<TAPS, NW>(st, wx, b, roww, y);
+			if (four)     roll_block<TAPS, P2, NW, 4>(st, wx, b, bn, roww, y);
+			else if (one) roll_block<TAPS, P2, NW, 1>(st, wx, b, bn, roww, y);
+			else          roll_row_any<TAPS, P2, NW>(st, wx, b, roww, y);
 			r += step;
 			b = bn;
 		}
@@ -812,18 +823,29 @@ fixca_launch_roll_batch(const void *const *d_src, void *const *d_dst, int n_imag
 	RollTables tb;
 	hipError_t e = ensure_tables(g, pl, stream, &tb);
 	if (e != hipSuccess) return e;
-	const size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
+	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
+	if (const char *e = getenv("FIXCA_EXP_LDS_PAD")) lds += (size_t)atoi(e);      /* timing experiment: fewer waves per CU */
 	static bool attr_done = false;
 	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void *)k_roll<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		attr_done = true;
 	}
 	const dim3 grid((unsigned)pl->nblocks * (unsigned)n_images);
-	if (g->interp == 0)      hipLaunchKernelGGL(k_roll<1>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-	else if (g->interp == 1) hipLaunchKernelGGL(k_roll<2>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-	else                     hipLaunchKernelGGL(k_roll<4>, grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	const bool p2 = (pl->ring & (pl->ring - 1)) == 0;
+	if (p2) {
+		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+		else                     hipLaunchKernelGGL((k_roll<4, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	} else {
+		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+		else                     hipLaunchKernelGGL((k_roll<4, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+	}
 	return hipGetLastError();
 }
 
