@@ -15,6 +15,8 @@ struct FixcaGeom {
 	int    xc, yc;      /* lens centre, C-truncated (fix-ca.c:1033-1034)    */
 	int    y1, y2;      /* rows to produce                                   */
 	int    interp;      /* 0 none, 1 linear, 2 cubic                         */
+	int    bpc;         /* color_size() code: 1 u8, 2 u16, 4 u32, -4 float, -8 double */
+	int    nch;         /* samples per pixel: 3 (RGB) or 4 (RGBA) = bpp / |bpc| */
 	double s[2];        /* scale about the centre (fix-ca.c:1044-1045)      */
 	double xs[2];       /* directional x shift                               */
 	double ys[2];       /* directional y shift                               */

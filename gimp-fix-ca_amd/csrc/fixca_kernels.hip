@@ -117,6 +117,106 @@ k_exact(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g)
 }
 
 /* ------------------------------------------------------------------------ */
+/* k_wide: the same fp64 arithmetic for 16/32-bit and floating-point samples  */
+/* (get_pixel / set_pixel, fix-ca.c:713-774): bit-exact, one thread per pixel  */
+/* ------------------------------------------------------------------------ */
+
+template <typename S> struct SampleCodec;
+template <> struct SampleCodec<uint16_t> {
+	static __device__ __forceinline__ double get(uint16_t s) { return __ddiv_rn((double)s, 65535.0); }
+	static __device__ __forceinline__ uint16_t put(double d) { return (uint16_t)round(__dmul_rn(d, 65535.0)); }
+};
+template <> struct SampleCodec<uint32_t> {
+	static __device__ __forceinline__ double get(uint32_t s) { return __ddiv_rn((double)s, 4294967295.0); }
+	static __device__ __forceinline__ uint32_t put(double d) { return (uint32_t)round(__dmul_rn(d, 4294967295.0)); }
+};
+template <> struct SampleCodec<float> {
+	static __device__ __forceinline__ double get(float s) { return (double)s; }
+	static __device__ __forceinline__ float put(double d) { return (float)d; }
+};
+template <> struct SampleCodec<double> {
+	static __device__ __forceinline__ double get(double s) { return s; }
+	static __device__ __forceinline__ double put(double d) { return d; }
+};
+
+template <typename S, int NCH>
+__global__ __launch_bounds__(256) void
+k_wide(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g)
+{
+	typedef SampleCodec<S> C;
+	const int x = blockIdx.x * 256 + threadIdx.x;
+	if (x >= g.W) return;
+	const size_t pitch = (size_t)g.W * NCH;              /* in samples */
+
+	for (int y = g.y1 + blockIdx.y; y < g.y2; y += gridDim.y) {
+		const S *in = src + (size_t)y * pitch + (size_t)x * NCH;
+		S px[NCH];
+#pragma unroll
+		for (int k = 0; k < NCH; ++k) px[k] = in[k];
+
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			const int off = 2 * c;
+			const double s = g.s[c], xs = g.xs[c], ys = g.ys[c];
+			if (g.interp == 0) {
+				int sy = map_int(y, g.yc, g.H, s, ys);
+				int sx = map_int(x, g.xc, g.W, s, xs);
+				px[off] = src[(size_t)sy * pitch + (size_t)sx * NCH + off];   /* a copy of the sample's bytes */
+			} else if (g.interp == 1) {
+				double yd = map_dbl(y, g.yc, g.H, s, ys);
+				double xd = map_dbl(x, g.xc, g.W, s, xs);
+				int r0 = (int)floor(yd), c0 = (int)floor(xd);
+				double fy = __dsub_rn(yd, (double)r0), fx = __dsub_rn(xd, (double)c0);
+				int r1 = (r0 == g.H - 1) ? r0 : r0 + 1;
+				int c1 = (c0 == g.W - 1) ? c0 : c0 + 1;
+				const S *row0 = src + (size_t)r0 * pitch + off;
+				const S *row1 = src + (size_t)r1 * pitch + off;
+				double p00 = C::get(row0[(size_t)c0 * NCH]), p10 = C::get(row0[(size_t)c1 * NCH]);
+				double p01 = C::get(row1[(size_t)c0 * NCH]), p11 = C::get(row1[(size_t)c1 * NCH]);
+				double a = __dadd_rn(p00, __dmul_rn(fx, __dsub_rn(p10, p00)));
+				double b = __dadd_rn(p01, __dmul_rn(fx, __dsub_rn(p11, p01)));
+				double v = __dadd_rn(__dmul_rn(__dsub_rn(1.0, fy), a), __dmul_rn(fy, b));
+				px[off] = C::put(clip01(v));
+			} else {
+				double yd = map_dbl(y, g.yc, g.H, s, ys);
+				double xd = map_dbl(x, g.xc, g.W, s, xs);
+				int r0 = (int)floor(yd), c0 = (int)floor(xd);
+				double fy = __dsub_rn(yd, (double)r0), fx = __dsub_rn(xd, (double)c0);
+				int rr[4], cc[4];
+				rr[1] = r0; rr[0] = (r0 == 0) ? r0 : r0 - 1;
+				rr[2] = (r0 == g.H - 1) ? r0 : r0 + 1;
+				rr[3] = (rr[2] == g.H - 1) ? rr[2] : rr[2] + 1;
+				cc[1] = c0; cc[0] = (c0 == 0) ? c0 : c0 - 1;
+				cc[2] = (c0 == g.W - 1) ? c0 : c0 + 1;
+				cc[3] = (cc[2] == g.W - 1) ? cc[2] : cc[2] + 1;
+				double h[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const S *row = src + (size_t)rr[j] * pitch + off;
+					h[j] = cr_exact(C::get(row[(size_t)cc[0] * NCH]), C::get(row[(size_t)cc[1] * NCH]),
+					                C::get(row[(size_t)cc[2] * NCH]), C::get(row[(size_t)cc[3] * NCH]), fx);
+				}
+				double v = cr_exact(h[0], h[1], h[2], h[3], fy);
+				px[off] = C::put(clip01(v));
+			}
+		}
+
+		S *out = dst + (size_t)y * pitch + (size_t)x * NCH;
+#pragma unroll
+		for (int k = 0; k < NCH; ++k) out[k] = px[k];
+	}
+}
+
+template <typename S>
+static void launch_wide(const void *d_src, void *d_dst, const FixcaGeom *g, dim3 grid, hipStream_t stream)
+{
+	const S *s = static_cast<const S *>(d_src);
+	S *d = static_cast<S *>(d_dst);
+	if (g->nch == 4) hipLaunchKernelGGL((k_wide<S, 4>), grid, dim3(256), 0, stream, s, d, *g);
+	else             hipLaunchKernelGGL((k_wide<S, 3>), grid, dim3(256), 0, stream, s, d, *g);
+}
+
+/* ------------------------------------------------------------------------ */
 /* shared pieces of the fast kernels                                         */
 /* ------------------------------------------------------------------------ */
 
@@ -498,8 +598,12 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 	case FIXCA_K_EXACT: {
 		int rows = g->y2 - g->y1;
 		dim3 grid((g->W + 255) / 256, rows < 65535 ? rows : 65535);
-		if (g->bpp == 4) hipLaunchKernelGGL(k_exact<4>, grid, dim3(256), 0, stream, s, d, *g);
-		else             hipLaunchKernelGGL(k_exact<3>, grid, dim3(256), 0, stream, s, d, *g);
+		if (g->bpc == 2)       launch_wide<uint16_t>(d_src, d_dst, g, grid, stream);
+		else if (g->bpc == 4)  launch_wide<uint32_t>(d_src, d_dst, g, grid, stream);
+		else if (g->bpc == -4) launch_wide<float>(d_src, d_dst, g, grid, stream);
+		else if (g->bpc == -8) launch_wide<double>(d_src, d_dst, g, grid, stream);
+		else if (g->bpp == 4)  hipLaunchKernelGGL(k_exact<4>, grid, dim3(256), 0, stream, s, d, *g);
+		else                   hipLaunchKernelGGL(k_exact<3>, grid, dim3(256), 0, stream, s, d, *g);
 		break;
 	}
 	case FIXCA_K_NONE:

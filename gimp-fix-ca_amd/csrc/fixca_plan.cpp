@@ -80,14 +80,21 @@ int fixca_make_geom(int W, int H, int bytes, int bpc, const FixCaParams *p,
 		return fixca_fail(FIXCA_E_UNSUPPORTED,
 		                  "column range [%d,%d) != [0,%d): the reference indexes partial columns wrongly "
 		                  "(fix-ca.c:855,1084,1098); only full-width calls are defined", x1, x2, W);
-	if (bpc != 1 || (bytes != 3 && bytes != 4))
-		return fixca_fail(FIXCA_E_UNSUPPORTED, "bpc=%d bytes=%d: only 8-bit RGB/RGBA is implemented", bpc, bytes);
+	/* color_size() codes (fix-ca.c:681-711): 1, 2, 4 unsigned integers, -4 float, -8 double.
+	 * 8 (u64) goes through long double in the reference (fix-ca.c:727-731, :763-766): no GPU
+	 * equivalent of x87 extended precision, so it is refused. */
+	const int sb = bpc < 0 ? -bpc : bpc;
+	if (!(bpc == 1 || bpc == 2 || bpc == 4 || bpc == -4 || bpc == -8) || (bytes != 3 * sb && bytes != 4 * sb))
+		return fixca_fail(FIXCA_E_UNSUPPORTED, "bpc=%d bytes=%d: implemented are RGB/RGBA with u8, u16, u32, float or double samples",
+		                  bpc, bytes);
 	if (!show_progress)
 		return fixca_fail(FIXCA_E_UNSUPPORTED, "preview path (show_progress=0: saturate+centerline) is not implemented");
 	if (p->interpolation < 0 || p->interpolation > 2)
 		return fixca_fail(FIXCA_E_DOMAIN, "interpolation %d not in 0..2", p->interpolation);
 
+	memset(g, 0, sizeof *g);
 	g->W = W; g->H = H; g->bpp = bytes;
+	g->bpc = bpc; g->nch = bytes / sb;
 	g->xc = trunc_to_int(p->lens_x);                      /* fix-ca.c:1033-1034 */
 	g->yc = trunc_to_int(p->lens_y);
 	g->y1 = y1; g->y2 = y2;
@@ -417,6 +424,13 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	memset(pl, 0, sizeof *pl);
 	pl->kernel = FIXCA_K_EXACT;
 	if (want == FIXCA_KERNEL_EXACT) return FIXCA_OK;
+	if (g->bpc != 1) {
+		/* 16/32-bit and floating-point samples: the fp64 kernel (bit-exact, one thread per pixel)
+		 * is the only implementation so far */
+		if (want == FIXCA_KERNEL_FAST)
+			return fixca_fail(FIXCA_E_UNSUPPORTED, "no fast kernel for bpc=%d yet", g->bpc);
+		return FIXCA_OK;
+	}
 
 	if (!getenv("FIXCA_NO_ROLL") && plan_roll(g, pl)) return FIXCA_OK;
 	memset(pl, 0, sizeof *pl);
@@ -459,7 +473,7 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 	static const char *in[] = { "none", "linear", "cubic" };
 	if (!buf || !n) return;
 	if (pl->kernel == FIXCA_K_EXACT)
-		snprintf(buf, n, "%s %s bpp=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, (g->W + 255) / 256, g->y2 - g->y1);
+		snprintf(buf, n, "%s %s bpp=%d bpc=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, g->bpc, (g->W + 255) / 256, g->y2 - g->y1);
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

@@ -66,9 +66,15 @@ def test_plan_refusals(kwargs, code):
 
 def test_plan_refuses_formats_and_domain():
     p = fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8)
-    for bytes_, bpc in ((8, 2), (16, -4), (2, 1), (5, 1)):
+    for bytes_, bpc in ((32, 8), (24, 8), (10, 2), (16, -8), (2, 1), (5, 1), (4, 3)):       # u64 needs x87 long double
         with pytest.raises(fixca.FixCaError) as e:
             fixca.plan(32, 16, bytes_, bpc, p)
+        assert e.value.code == fixca.E_UNSUPPORTED
+    for bytes_, bpc in ((8, 2), (6, 2), (16, 4), (16, -4), (12, -4), (32, -8)):     # u16, u32, float, double: fp64 kernel
+        k, desc = fixca.plan(32, 16, bytes_, bpc, p)
+        assert k == 1 and "bpc=%d" % bpc in desc
+        with pytest.raises(fixca.FixCaError) as e:
+            fixca.plan(32, 16, bytes_, bpc, p, kernel=fixca.KERNEL_FAST)
         assert e.value.code == fixca.E_UNSUPPORTED
     with pytest.raises(fixca.FixCaError) as e:      # max_dim 16 + (-20) <= 0
         fixca.plan(32, 16, 4, 1, fixca.make_params(blue=-20, lens_x=16, lens_y=8))

@@ -165,6 +165,48 @@ def test_integer_directional_shift_is_a_translation(torch_cuda):
         assert np.array_equal(out[..., 0], img[..., 0][ys][:, xs])
 
 
+# ---- 16/32-bit and floating-point samples ---------------------------
+
+WIDE = [(2, np.uint16), (4, np.uint32), (-4, np.float32), (-8, np.float64)]
+
+
+def _wide_image(dtype, w, h, nch, seed):
+    raw = synth.noise_bytes(seed, w * h * nch * 8).view(np.uint64)[: w * h * nch]
+    if np.issubdtype(dtype, np.integer):
+        return (raw & np.uint64(np.iinfo(dtype).max)).astype(dtype).reshape(h, w, nch)
+    # floats: mostly inside [0,1], some outside (the reference clips them in linear/cubic)
+    v = (raw >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return (v * 1.3 - 0.15).astype(dtype).reshape(h, w, nch)
+
+
+@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("nch", [3, 4])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_wide_samples_bit_exact(torch_cuda, bpc, dtype, nch, interp):
+    """get_pixel / set_pixel for u16, u32, float, double (fix-ca.c:713-774): the fp64 kernel must
+    reproduce the oracle bit for bit (the oracle itself has no reference vectors for these
+    precisions: DESIGN.md)."""
+    torch = torch_cuda
+    w, h = 157, 61
+    img = _wide_image(dtype, w, h, nch, 900 + abs(bpc) + nch)
+    p = fixca.make_params(blue=3.3, red=-2.4, lens_x=40, lens_y=21, interpolation=interp, x_blue=1.5, y_red=-2.25)
+    ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
+    sb = abs(bpc)
+    # device entry on raw bytes
+    src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+    dst = torch.zeros_like(src)
+    fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().view(dtype).reshape(h, w, nch)
+    assert got.tobytes() == ref.tobytes()
+    # host entry, row range
+    out = np.full_like(img, 7)
+    fixca.fix_ca_region(img, out, w, h, nch * sb, bpc, p, 0, w, 5, h - 9, True)
+    assert out[5:h - 9].tobytes() == ref[5:h - 9].tobytes()
+    assert np.all(out[:5] == 7) and np.all(out[h - 9:] == 7)
+    fixca.lib.fixca_release_cache()
+
+
 # ---- the host-pointer entry (what the plug-in calls) --------------------------------
 
 @pytest.mark.parametrize("interp", [0, 1, 2])
