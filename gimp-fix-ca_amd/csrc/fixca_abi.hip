@@ -15,6 +15,7 @@
 
 extern "C" hipError_t fixca_launch(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_copy(const void *, void *, size_t, hipStream_t);
+extern "C" hipError_t fixca_launch_centerline(void *, const FixcaGeom *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
 /* a batch of images of one geometry: the row-rolling kernel takes up to 32 per launch, the
@@ -118,6 +119,8 @@ extern "C" int fixca_region_device(const void *d_src, void *d_dst, int W, int H,
 	rc = fixca_make_plan(&g, flags, &pl);
 	if (rc) return rc;
 	HIP_TRY(fixca_launch(d_src, d_dst, &g, &pl, (hipStream_t)stream));
+	if (g.preview)                               /* fix-ca.c:1322-1327, after the row's pixels are final */
+		HIP_TRY(fixca_launch_centerline(d_dst, &g, (hipStream_t)stream));
 	return FIXCA_OK;
 }
 

@@ -17,6 +17,8 @@ struct FixcaGeom {
 	int    interp;      /* 0 none, 1 linear, 2 cubic                         */
 	int    bpc;         /* color_size() code: 1 u8, 2 u16, 4 u32, -4 float, -8 double */
 	int    nch;         /* samples per pixel: 3 (RGB) or 4 (RGBA) = bpp / |bpc| */
+	int    preview;     /* show_progress == 0: draw the lens-centre lines afterwards (fix-ca.c:1326) */
+	int    pad_;
 	double s[2];        /* scale about the centre (fix-ca.c:1044-1045)      */
 	double xs[2];       /* directional x shift                               */
 	double ys[2];       /* directional y shift                               */

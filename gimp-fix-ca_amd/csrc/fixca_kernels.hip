@@ -570,6 +570,57 @@ k_interp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g
 }
 
 /* ------------------------------------------------------------------------ */
+/* k_centerline: the preview's dashed lens-centre lines (fix-ca.c:945-996),   */
+/* drawn over rows [y1,y2) of the result.  One workgroup per row.             */
+/* ------------------------------------------------------------------------ */
+
+template <typename S>
+__global__ __launch_bounds__(256) void
+k_centerline(S *__restrict__ dst, FixcaGeom g, S one)
+{
+	const int y = g.y1 + blockIdx.x;
+	const int W = g.W, nch = g.nch;
+	S *row = dst + (size_t)y * W * nch;
+	if (y == g.yc) {
+		/* the reference walks the row with a counter: the first run is i0 + 2 pixels long, every
+		 * later run 9 pixels, alternating 0 and 1 (i = |xc| % 16; starts at 0 if i < 8) */
+		const int i0 = abs(g.xc) % 16;
+		const int c0 = (i0 < 8) ? 0 : 1;
+		for (int x = threadIdx.x; x < W; x += 256) {
+			const int c = (x <= i0 + 1) ? c0 : (c0 ^ ((((x - (i0 + 2)) / 9) + 1) & 1));
+			const S v = c ? one : (S)0;
+			row[(size_t)x * nch] = v; row[(size_t)x * nch + 1] = v; row[(size_t)x * nch + 2] = v;
+		}
+		return;
+	}
+	if (threadIdx.x < 3) {
+		const int d = abs(y - g.yc);
+		const S v = ((d % 16) < 8) ? (S)0 : one;
+		const int x = threadIdx.x == 0 ? g.xc : (threadIdx.x == 1 ? g.xc - d : g.xc + d);
+		if (x >= 0 && x < W) {
+			row[(size_t)x * nch] = v; row[(size_t)x * nch + 1] = v; row[(size_t)x * nch + 2] = v;
+		}
+	}
+}
+
+extern "C" hipError_t
+fixca_launch_centerline(void *d_dst, const FixcaGeom *g, hipStream_t stream)
+{
+	const int rows = g->y2 - g->y1;
+	if (rows <= 0) return hipSuccess;
+	const dim3 grid(rows), block(256);
+	switch (g->bpc) {
+	case 1:  hipLaunchKernelGGL(k_centerline<uint8_t>, grid, block, 0, stream, static_cast<uint8_t *>(d_dst), *g, (uint8_t)255); break;
+	case 2:  hipLaunchKernelGGL(k_centerline<uint16_t>, grid, block, 0, stream, static_cast<uint16_t *>(d_dst), *g, (uint16_t)65535); break;
+	case 4:  hipLaunchKernelGGL(k_centerline<uint32_t>, grid, block, 0, stream, static_cast<uint32_t *>(d_dst), *g, 4294967295u); break;
+	case -4: hipLaunchKernelGGL(k_centerline<float>, grid, block, 0, stream, static_cast<float *>(d_dst), *g, 1.0f); break;
+	case -8: hipLaunchKernelGGL(k_centerline<double>, grid, block, 0, stream, static_cast<double *>(d_dst), *g, 1.0); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
 /* bandwidth yardstick: 16 bytes per lane straight copy                      */
 /* ------------------------------------------------------------------------ */
 

@@ -87,14 +87,18 @@ int fixca_make_geom(int W, int H, int bytes, int bpc, const FixCaParams *p,
 	if (!(bpc == 1 || bpc == 2 || bpc == 4 || bpc == -4 || bpc == -8) || (bytes != 3 * sb && bytes != 4 * sb))
 		return fixca_fail(FIXCA_E_UNSUPPORTED, "bpc=%d bytes=%d: implemented are RGB/RGBA with u8, u16, u32, float or double samples",
 		                  bpc, bytes);
-	if (!show_progress)
-		return fixca_fail(FIXCA_E_UNSUPPORTED, "preview path (show_progress=0: saturate+centerline) is not implemented");
+	/* show_progress == 0 is preview_update()'s call (fix-ca.c:656): after the row loop the
+	 * reference boosts saturation (only if saturation != 0; that uses libgimpcolor's HSV
+	 * conversion, which is not in the reference tree: refused) and draws the lens-centre lines. */
+	if (!show_progress && p->saturation != 0.0)
+		return fixca_fail(FIXCA_E_UNSUPPORTED, "preview saturation boost (saturation=%g) is not implemented", p->saturation);
 	if (p->interpolation < 0 || p->interpolation > 2)
 		return fixca_fail(FIXCA_E_DOMAIN, "interpolation %d not in 0..2", p->interpolation);
 
 	memset(g, 0, sizeof *g);
 	g->W = W; g->H = H; g->bpp = bytes;
 	g->bpc = bpc; g->nch = bytes / sb;
+	g->preview = show_progress ? 0 : 1;
 	g->xc = trunc_to_int(p->lens_x);                      /* fix-ca.c:1033-1034 */
 	g->yc = trunc_to_int(p->lens_y);
 	g->y1 = y1; g->y2 = y2;

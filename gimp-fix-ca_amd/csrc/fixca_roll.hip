@@ -736,6 +736,7 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 {
 	FixcaGeom key = *g;
 	key.y1 = key.y2 = 0;
+	key.preview = 0;
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;

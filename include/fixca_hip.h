@@ -34,7 +34,7 @@ extern "C" {
 #define FIXCA_E_INVALID      (-1)  /* null pointer, non-positive size, bad row range   */
 #define FIXCA_E_UNSUPPORTED  (-2)  /* x1 != 0 or x2 != orig_width (reference indexes
                                       wrongly there); bpc/bytes pair not
-                                      implemented; preview path (show_progress == 0)  */
+                                      implemented; preview saturation boost           */
 #define FIXCA_E_DOMAIN       (-3)  /* max_dim + amount <= 0, |amount| > 30, interp ∉ 0..2 */
 #define FIXCA_E_HIP          (-4)  /* a HIP runtime call failed                        */
 #define FIXCA_E_NODEVICE     (-5)  /* no gfx950 device visible                         */

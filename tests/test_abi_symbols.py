@@ -55,13 +55,22 @@ def test_params_check_matches_run_range():
     (dict(y1=-1), fixca.E_INVALID),
     (dict(y2=99), fixca.E_INVALID),
     (dict(y1=9, y2=3), fixca.E_INVALID),
-    (dict(show_progress=False), fixca.E_UNSUPPORTED),
 ])
 def test_plan_refusals(kwargs, code):
     p = fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8)
     with pytest.raises(fixca.FixCaError) as e:
         fixca.plan(32, 16, 4, 1, p, **kwargs)
     assert e.value.code == code and str(e.value)
+
+
+def test_preview_call_is_planned_unless_it_needs_saturation():
+    p = fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8)
+    assert fixca.plan(32, 16, 4, 1, p, show_progress=False)[0] >= 1          # preview_update()'s call: centre lines
+    q = fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8, saturation=25.0)
+    assert fixca.plan(32, 16, 4, 1, q, show_progress=True)[0] >= 1           # ignored in the final render
+    with pytest.raises(fixca.FixCaError) as e:
+        fixca.plan(32, 16, 4, 1, q, show_progress=False)                      # HSV boost: libgimpcolor, unpinned
+    assert e.value.code == fixca.E_UNSUPPORTED
 
 
 def test_plan_refuses_formats_and_domain():

@@ -165,6 +165,35 @@ def test_integer_directional_shift_is_a_translation(torch_cuda):
         assert np.array_equal(out[..., 0], img[..., 0][ys][:, xs])
 
 
+# ---- the preview caller: show_progress = 0 draws the lens-centre lines ------
+
+@pytest.mark.parametrize("lens", [(40, 21), (0, 0), (-1, -1), (156, 60), (300, 30), (77, -5)], ids=str)
+@pytest.mark.parametrize("interp", [0, 2])
+def test_preview_centre_lines(torch_cuda, lens, interp):
+    """preview_update() calls fix_ca_region with show_progress = FALSE on a row range
+    (fix-ca.c:656): the result rows then carry the dashed lens-centre lines (fix-ca.c:945-996).
+    Checked against the oracle's restatement (no reference vector exists for this branch)."""
+    w, h = 157, 61
+    p = fixca.make_params(blue=2.0, red=-1.5, lens_x=lens[0], lens_y=lens[1], interpolation=interp)
+    po = pyoracle.make_params(**p.as_dict())
+    for c, (bpc, dtype) in ((4, (1, np.uint8)), (3, (1, np.uint8)), (4, (2, np.uint16)), (3, (-4, np.float32))):
+        img = _wide_image(dtype, w, h, c, 33 + c) if bpc != 1 else synth.noise_image(33 + c, w, h, c)
+        sb = abs(bpc)
+        for y1, y2 in ((0, h), (15, 40)):
+            ref = np.full_like(img, 3)
+            pyoracle.region(img, po, bpc=bpc, y1=y1, y2=y2, show_progress=0, dst=ref)
+            out = np.full_like(img, 3)
+            fixca.fix_ca_region(img, out, w, h, c * sb, bpc, p, 0, w, y1, y2, False)
+            if interp == 0 or bpc != 1:
+                assert out.tobytes() == ref.tobytes()
+            else:
+                mx, _ = diff_stats(out, ref)
+                assert mx <= TOL_LSB
+                lines = (ref != pyoracle.region(img, po, bpc=bpc, y1=y1, y2=y2, dst=np.full_like(img, 3)))
+                assert np.array_equal(out[lines], ref[lines])           # the lines themselves are exact
+    fixca.lib.fixca_release_cache()
+
+
 # ---- 16/32-bit and floating-point samples (SURVEY 8f row 1) ---------------------------
 
 WIDE = [(2, np.uint16), (4, np.uint32), (-4, np.float32), (-8, np.float64)]
