@@ -165,6 +165,47 @@ def test_integer_directional_shift_is_a_translation(torch_cuda):
         assert np.array_equal(out[..., 0], img[..., 0][ys][:, xs])
 
 
+# ---- seeded fuzz over geometry and parameters: planner conditions vs kernel assumptions ----------
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n):
+        w = int(rng.integers(64, 700)) * 4
+        h = int(rng.integers(12, 150))
+        mag = [0.3, 1.0, 3.0, 10.0, 30.0][k % 5]                 # up to the plug-in's +-30 limit
+        kw = dict(blue=float(rng.uniform(-mag, mag)), red=float(rng.uniform(-mag, mag)),
+                  lens_x=float(rng.integers(-2, w + 2)), lens_y=float(rng.integers(-2, h + 2)),
+                  x_blue=float(rng.uniform(-mag, mag)) if k % 3 == 0 else 0.0,
+                  x_red=float(rng.uniform(-mag, mag)) if k % 3 == 0 else 0.0,
+                  y_blue=float(rng.uniform(-mag, mag)) if k % 4 == 0 else 0.0,
+                  y_red=float(rng.uniform(-mag, mag)) if k % 4 == 0 else 0.0)
+        if k % 7 == 0:                                           # integer shifts: fractions exactly 0
+            kw.update(blue=0.0, red=0.0, x_blue=float(rng.integers(-3, 4)), y_red=float(rng.integers(-3, 4)))
+        cases.append((w, h, kw))
+    return cases
+
+
+@pytest.mark.parametrize("idx", range(60))
+def test_fuzz_auto_kernel_against_oracle(torch_cuda, idx):
+    w, h, kw = _fuzz_cases(60, 0xF1CA)[idx]
+    img = synth.noise_image(5000 + idx, w, h, 4)
+    y1, y2 = (0, h) if idx % 2 else (h // 4, h - 3)
+    for interp in (0, 1, 2):
+        p = fixca.make_params(interpolation=interp, **kw)
+        try:
+            kid, desc = fixca.plan(w, h, 4, 1, p, y1=y1, y2=y2)
+        except fixca.FixCaError as e:
+            assert e.code == fixca.E_DOMAIN                      # max_dim + amount <= 0
+            continue
+        ref = oracle_run(img, p)
+        out = gpu_run(torch_cuda, img, p, fixca.KERNEL_AUTO, y1=y1, y2=y2, fill=0x6B)
+        mx, n = diff_stats(out[y1:y2], ref[y1:y2])
+        assert mx <= (0 if interp == 0 else TOL_LSB), (desc, kw, mx, n)
+        assert n <= 0.02 * ref[y1:y2].size, (desc, kw, n)
+        assert np.all(out[:y1] == 0x6B) and np.all(out[y2:] == 0x6B)
+
+
 # ---- the preview caller: show_progress = 0 draws the lens-centre lines ------
 
 @pytest.mark.parametrize("lens", [(40, 21), (0, 0), (-1, -1), (156, 60), (300, 30), (77, -5)], ids=str)
