@@ -17,6 +17,7 @@ extern "C" hipError_t fixca_launch(const void *, void *, const FixcaGeom *, cons
 extern "C" hipError_t fixca_launch_copy(const void *, void *, size_t, hipStream_t);
 extern "C" hipError_t fixca_launch_centerline(void *, const FixcaGeom *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_roll_batch_rgb(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
 /* a batch of images of one geometry: the row-rolling kernel takes up to 32 per launch, the
  * other kernels one */
@@ -148,7 +149,8 @@ static int launch_many(const void *const *d_src, void *const *d_dst, int n, cons
 	if (pl->kernel == FIXCA_K_ROLL && g->y2 > g->y1) {
 		for (int i = 0; i < n; i += 32) {
 			const int m = n - i < 32 ? n - i : 32;
-			HIP_TRY(fixca_launch_roll_batch(d_src + i, d_dst + i, m, g, pl, stream));
+			if (g->bpp == 3) HIP_TRY(fixca_launch_roll_batch_rgb(d_src + i, d_dst + i, m, g, pl, stream));
+			else             HIP_TRY(fixca_launch_roll_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			++count;
 		}
 	} else {
@@ -166,10 +168,12 @@ static void  *g_cache[2] = { NULL, NULL };
 static size_t g_cache_bytes = 0;
 
 extern "C" void fixca_roll_release_tables(void);
+extern "C" void fixca_roll_release_tables_rgb(void);
 
 extern "C" void fixca_release_cache(void)
 {
 	fixca_roll_release_tables();
+	fixca_roll_release_tables_rgb();
 	for (int i = 0; i < 2; ++i) {
 		if (g_cache[i]) (void)hipFree(g_cache[i]);
 		g_cache[i] = NULL;

@@ -638,6 +638,7 @@ k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 
 extern "C" hipError_t fixca_launch_scan(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_roll_rgb(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
 extern "C" hipError_t
 fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
@@ -674,7 +675,7 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 	case FIXCA_K_SCANW:
 		return fixca_launch_scan(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_ROLL:
-		return fixca_launch_roll(d_src, d_dst, g, pl, stream);
+		return g->bpp == 3 ? fixca_launch_roll_rgb(d_src, d_dst, g, pl, stream) : fixca_launch_roll(d_src, d_dst, g, pl, stream);
 	default:
 		return hipErrorInvalidValue;
 	}

@@ -312,8 +312,8 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 
 static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 {
-	if (g->bpp != 4 || (g->W & 3) || g->W < FIXCA_WAVE_COLS) return false;
-	if ((long long)g->W * g->H * 4 > (1LL << 31)) return false;            /* 32-bit buffer offsets, see k_roll */
+	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < FIXCA_WAVE_COLS) return false;
+	if ((long long)g->W * g->H * g->bpp > (1LL << 31)) return false;       /* 32-bit buffer offsets, see k_roll */
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* a block of 4 output rows keeps span + 3 rows alive; leave >= 2 slots for rows in flight */
@@ -351,7 +351,7 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 		 * first window); a row time grows with the k = ceil(waves / 256) waves sharing a CU about
 		 * as 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9): mostly latency, partly
 		 * throughput. */
-		int per_cu = (160 * 1024) / (ring * 1024 + 512);
+		int per_cu = (160 * 1024) / (ring * 256 * g->bpp + 512);
 		if (per_cu > 7) per_cu = 7;                     /* measured: 7 waves per CU beat 8 and 9 at equal total rows */
 		int best_th = 0;
 		long best_cost = 0;

@@ -17,7 +17,7 @@
 /* one strip of `oc` output columns (16 bytes) */
 struct RollStrip {
 	int U0;             /* first column of the 256-column source window (multiple of 4)          */
-	int tapR, tapB;     /* byte offset, in a ring row, of lane 0's 4-pixel tap window (may be < 0) */
+	int tapR, tapB;     /* pixel offset, in a ring row, of lane 0's 4-pixel tap window (may be < 0) */
 	int gen;            /* 1: some output of the strip needs the 5th weight (step or image edge)  */
 };
 

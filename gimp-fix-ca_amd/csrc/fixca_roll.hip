@@ -53,7 +53,23 @@ typedef float        f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-#define RING_ROW    1024                /* bytes per ring row: 256 px x 4 B                      */
+/* This file is compiled twice: for RGBA8 (4 bytes per pixel, the default) and, through
+ * fixca_roll_rgb.hip, for RGB8 (3 bytes per pixel).  Everything that depends on the pixel size
+ * hangs on ROLL_BPP; entry points and kernels get a suffix so both can live in one library. */
+#ifndef ROLL_BPP
+#define ROLL_BPP 4
+#endif
+#if ROLL_BPP == 4
+#define ROLL_NAME(x) x
+#else
+#define ROLL_NAME(x) x##_rgb
+#define k_roll        k_roll_rgb
+#define k_roll_tables k_roll_tables_rgb
+#endif
+
+#define RING_ROW    (256 * ROLL_BPP)    /* bytes per ring row: 256 px                             */
+
+namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
 #define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
 #define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
 #define RDEPTH      6                   /* source rows kept in flight beyond the newest row in use */
@@ -164,8 +180,20 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
 	++st.ld;
 	const int slot = roll_slot(st, st.ld);
 #if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
+#if ROLL_BPP == 4
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW),
 	                                         16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
+#else
+	/* A 12-byte LDS-DMA puts lane L's bytes at 16 L (a 4-byte hole after every 4 pixels), so the
+	 * 768-byte row segment is moved as three 256-byte pieces of one dword per lane instead: the
+	 * ring row stays contiguous.  (The instruction offset applies to the global AND the LDS
+	 * address, so all three use the same LDS base.)  Three loads per row: roll_fetch counts
+	 * accordingly. */
+	__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(st.ring + slot * RING_ROW);
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 256, ROLL_LD_AUX);
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 512, ROLL_LD_AUX);
+#endif
 #endif
 	st.so_ld += st.pitch;
 }
@@ -175,8 +203,8 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
  * vmcnt counts loads and stores together.  Loads complete in order among loads and stores among
  * stores, but the compiler's own model of gfx9-family hardware does not order a load against a
  * store (a young store may be acknowledged before an old load has landed), so the wait relies
- * on loads only: rows are loaded in order, one load each, so exactly ld - need loads are
- * younger than the one needed, and "at most ld - need operations outstanding" implies "at most
+ * on loads only: rows are loaded in order, one load each (three for RGB), so exactly ld - need
+ * rows' loads are younger than the one needed, and "at most ld - need operations outstanding" implies "at most
  * ld - need loads outstanding", which implies the needed row is in LDS.  Stores in flight make
  * the wait stricter, never wrong. */
 template <int TAPS, bool P2>
@@ -187,46 +215,87 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
 #if defined(FIXCA_EXP_NOVMWAIT)                 /* timing experiment only: reads rows that may not have landed */
 	return;
 #endif
+	constexpr int LPR = (ROLL_BPP == 4) ? 1 : 3;     /* loads per row */
 	const int younger = st.ld - need;
-	if (younger >= 8) roll_wait_vm<8>();
-	else if (younger >= 6) roll_wait_vm<6>();
-	else if (younger >= 4) roll_wait_vm<4>();
-	else if (younger >= 2) roll_wait_vm<2>();
+	if (younger >= 8) roll_wait_vm<8 * LPR>();
+	else if (younger >= 6) roll_wait_vm<6 * LPR>();
+	else if (younger >= 4) roll_wait_vm<4 * LPR>();
+	else if (younger >= 2) roll_wait_vm<2 * LPR>();
+	else if (LPR > 1 && younger >= 1) roll_wait_vm<LPR>();
 	else roll_wait_vm<0>();
 }
 
-/* 16 bytes of ring row `row` at a 16-byte aligned offset */
+/* my 4 output pixels' own source pixels of ring row `row`: 16 bytes at a 16-byte aligned offset
+ * (RGBA) or 12 bytes at a 4-byte aligned offset (RGB; .w unused) */
+struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(4))) RollPx3 { uint32_t a, b, c; };
 template <int TAPS, bool P2>
 __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int row, uint32_t off)
 {
+#if ROLL_BPP == 4
 	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
+#else
+	const RollPx3 v = *reinterpret_cast<const RollPx3 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
+	return u32x4{ v.a, v.b, v.c, 0u };
+#endif
 }
 
-/* 16 bytes of ring row `row` at a pixel (4-byte) aligned offset.  A ds_read_b128 from an address
- * that is not 16-byte aligned returns the right data on gfx950 but takes ~65 LDS cycles instead
- * of 4 (measured), so the access is left to the compiler as 4-byte aligned: two ds_read2_b32. */
-struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
+/* the 4 pixels of my tap window of ring row `row`, at a pixel aligned offset.
+ * RGBA: 16 bytes at a 4-byte aligned address.  A ds_read_b128 from an address that is not 16-byte
+ * aligned returns the right data on gfx950 but takes ~65 LDS cycles instead of 4 (measured), so
+ * the access is left to the compiler as 4-byte aligned: two ds_read2_b32.
+ * RGB: 12 bytes at ANY byte address (3 bytes per pixel): the 16 bytes around them are read from
+ * the 4-byte aligned address below and shifted down by the (wave-uniform) misalignment. */
 template <int TAPS, bool P2>
 __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2> &st, int row, int off)
 {
 #if defined(FIXCA_EXP_ALIGNED)                  /* timing experiment only: wrong pixels */
 	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~15));
-#else
+#elif ROLL_BPP == 4
 	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, v.d };
+#else
+	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~3));
+	const uint32_t r = (uint32_t)off & 3u;
+	return u32x4{ __builtin_amdgcn_alignbyte(v.b, v.a, r), __builtin_amdgcn_alignbyte(v.c, v.b, r),
+	              __builtin_amdgcn_alignbyte(v.d, v.c, r), 0u };
 #endif
 }
+
+#if ROLL_BPP == 3
+/* the dword lane L + 1 holds (0 in lane 63); the sources here are VALU results, so the shift is
+ * left to the compiler, which knows the DPP hazards */
+__device__ __forceinline__ uint32_t next_lane_dword(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float ubyte_f32(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+#endif
 
 /* the 8 (NP used) pixels of my window of one source row per channel, as (red, blue) floats */
 template <int NP>
 __device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, f32x2 (&tp)[NP])
 {
+#if ROLL_BPP == 4
 #pragma unroll
 	for (int k = 0; k < 4; ++k)
 		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
 #pragma unroll
 	for (int k = 4; k < NP; ++k)
 		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
+#else
+	/* 12 bytes [R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3]: red of pixel k is byte 3k, blue byte 3k + 2 */
+	tp[0] = f32x2{ ubyte_f32(pr[0], 0), ubyte_f32(pb[0], 2) };
+	tp[1] = f32x2{ ubyte_f32(pr[0], 3), ubyte_f32(pb[1], 1) };
+	tp[2] = f32x2{ ubyte_f32(pr[1], 2), ubyte_f32(pb[2], 0) };
+	tp[3] = f32x2{ ubyte_f32(pr[2], 1), ubyte_f32(pb[2], 3) };
+	const uint32_t nr0 = next_lane_dword(pr[0]), nr1 = next_lane_dword(pr[1]), nr2 = next_lane_dword(pr[2]);
+	const uint32_t nb0 = next_lane_dword(pb[0]), nb1 = next_lane_dword(pb[1]), nb2 = next_lane_dword(pb[2]);
+	if (NP > 4) tp[4] = f32x2{ ubyte_f32(nr0, 0), ubyte_f32(nb0, 2) };
+	if (NP > 5) tp[5 < NP ? 5 : 0] = f32x2{ ubyte_f32(nr0, 3), ubyte_f32(nb1, 1) };
+	if (NP > 6) tp[6 < NP ? 6 : 0] = f32x2{ ubyte_f32(nr1, 2), ubyte_f32(nb2, 0) };
+	if (NP > 7) tp[7 < NP ? 7 : 0] = f32x2{ ubyte_f32(nr2, 1), ubyte_f32(nb2, 3) };
+#endif
 }
 
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
@@ -261,19 +330,34 @@ __device__ __forceinline__ void roll_wy(cfloat_p roww, int y, f32x2 (&wy)[TAPS])
 template <int TAPS, bool P2>
 __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 (&acc)[4], const u32x4 &idt)
 {
-	u32x4 out;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].x, 0, idt[k]);
-		out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
-	}
 	/* The row offset is added into the vector offset on purpose.  With the row offset in the
 	 * scalar-offset operand hipcc emits no wait state between a 16-byte buffer store and the
 	 * next write of its data registers (its hazard table exempts stores with an SGPR soffset);
 	 * on MI355X that store then picks up the NEXT row's bytes in the last quarter of each
 	 * 16-lane group (seen as sporadic wrong pixels).  With a constant soffset the compiler
 	 * handles the hazard. */
+#if ROLL_BPP == 4
+	u32x4 out;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].x, 0, idt[k]);
+		out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
+	}
 	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
+#else
+	/* [R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3] */
+	typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+	uint32_t o0 = idt[0], o1 = idt[1], o2 = idt[2];
+	o0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[0].x, 0, o0);
+	o0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[0].y, 2, o0);
+	o0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[1].x, 3, o0);
+	o1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[1].y, 1, o1);
+	o1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[2].x, 2, o1);
+	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[2].y, 0, o2);
+	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].x, 1, o2);
+	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].y, 3, o2);
+	__builtin_amdgcn_raw_buffer_store_b96(u32x3{ o0, o1, o2 }, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
+#endif
 	st.so_st += st.pitch;
 	/* stores are not counted by the fetch function's wait: see there */
 }
@@ -430,11 +514,11 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	st.KM = pl.ring - 1;
 	st.kmagic = (uint32_t)((0x100000000ull + (unsigned)pl.ring - 1) / (unsigned)pl.ring);
 	st.H = H;
-	st.pitch = (uint32_t)W * 4u;
+	st.pitch = (uint32_t)W * ROLL_BPP;
 	st.ring = lds + RING_PAD_LO;
 	{
 		/* descriptors are built from kernel arguments only, so they are provably wave-uniform */
-		const uint32_t total = (uint32_t)W * (uint32_t)H * 4u;      /* <= 2 GB: the planner checks */
+		const uint32_t total = (uint32_t)W * (uint32_t)H * ROLL_BPP;   /* <= 2 GB: the planner checks */
 		st.rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, total, 0x00020000);
 		st.rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total, 0x00020000);
 	}
@@ -450,7 +534,7 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 
 	/* start filling the ring before anything else */
 	st.ld = b.keep - 1;
-	st.vo_ld = (uint32_t)(U0 + 4 * lane) * 4u;
+	st.vo_ld = (ROLL_BPP == 4) ? (uint32_t)(U0 + 4 * lane) * 4u : (uint32_t)U0 * 3u + 4u * (uint32_t)lane;
 	st.so_ld = (uint32_t)b.keep * st.pitch;
 	{
 		const int target = min(min(b.need1 + RDEPTH, b.keep + st.KM), st.lastneed);
@@ -475,12 +559,12 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	}
 	/* lanes past the last producing lane only serve as its DPP neighbour: they all read where
 	 * lane `nact` reads, so a narrow last strip never reads far outside its ring row */
-	st.tap[0] = hd.tapR + 16 * min(lane, nact);
-	st.tap[1] = hd.tapB + 16 * min(lane, nact);
-	st.my_idt = (uint32_t)((X0 - U0) * 4) + (uint32_t)min(lane, nact - 1) * 16;
+	st.tap[0] = (hd.tapR + 4 * min(lane, nact)) * ROLL_BPP;
+	st.tap[1] = (hd.tapB + 4 * min(lane, nact)) * ROLL_BPP;
+	st.my_idt = (uint32_t)((X0 - U0) + 4 * min(lane, nact - 1)) * ROLL_BPP;
 	/* a lane without output stores at offset `total`: past the end whether or not the range check
 	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
-	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * 4u : (uint32_t)W * (uint32_t)H * 4u;
+	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : (uint32_t)W * (uint32_t)H * ROLL_BPP;
 	st.so_st = (uint32_t)Y0 * st.pitch;
 
 	auto run = [&](auto nw_tag) {
@@ -693,8 +777,8 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 	if (lane == 0) {
 		RollStrip h;
 		h.U0 = U0;
-		h.tapR = (X0 + mlo[0] - U0) * 4;
-		h.tapB = (X0 + mlo[1] - U0) * 4;
+		h.tapR = X0 + mlo[0] - U0;
+		h.tapB = X0 + mlo[1] - U0;
 		h.gen = gen ? 1 : 0;
 		tb.strips[strip] = h;
 	}
@@ -723,7 +807,7 @@ thread_local TableEntry g_tc[TABLE_ENTRIES];
 thread_local unsigned long long g_tick = 0;
 }
 
-extern "C" void fixca_roll_release_tables(void)
+extern "C" void ROLL_NAME(fixca_roll_release_tables)(void)
 {
 	for (TableEntry &e : g_tc) {
 		if (e.mem) (void)hipFree(e.mem);
@@ -812,7 +896,7 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 
 /* n_images images (1 .. ROLL_BATCH_MAX) in one launch */
 extern "C" hipError_t
-fixca_launch_roll_batch(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g,
+ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g,
                         const FixcaPlan *pl, hipStream_t stream)
 {
 	if (n_images < 1 || n_images > ROLL_BATCH_MAX) return hipErrorInvalidValue;
@@ -851,7 +935,9 @@ fixca_launch_roll_batch(const void *const *d_src, void *const *d_dst, int n_imag
 }
 
 extern "C" hipError_t
-fixca_launch_roll(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+ROLL_NAME(fixca_launch_roll)(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
-	return fixca_launch_roll_batch(&d_src, &d_dst, 1, g, pl, stream);
+	return ROLL_NAME(fixca_launch_roll_batch)(&d_src, &d_dst, 1, g, pl, stream);
 }
+
+}   /* namespace */

@@ -189,12 +189,13 @@ def _fuzz_cases(n, seed):
 @pytest.mark.parametrize("idx", range(60))
 def test_fuzz_auto_kernel_against_oracle(torch_cuda, idx):
     w, h, kw = _fuzz_cases(60, 0xF1CA)[idx]
-    img = synth.noise_image(5000 + idx, w, h, 4)
+    c = 3 if idx % 3 == 1 else 4                                 # RGB for a third of the cases
+    img = synth.noise_image(5000 + idx, w, h, c)
     y1, y2 = (0, h) if idx % 2 else (h // 4, h - 3)
     for interp in (0, 1, 2):
         p = fixca.make_params(interpolation=interp, **kw)
         try:
-            kid, desc = fixca.plan(w, h, 4, 1, p, y1=y1, y2=y2)
+            kid, desc = fixca.plan(w, h, c, 1, p, y1=y1, y2=y2)
         except fixca.FixCaError as e:
             assert e.code == fixca.E_DOMAIN                      # max_dim + amount <= 0
             continue
