@@ -89,11 +89,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible")
+    # FIXCA_BENCH_REHEARSE=1: several ranks share the one GPU of a test box and talk over gloo, to
+    # rehearse the N > 1 control flow; the real run is one rank per GPU over RCCL
+    rehearse = os.environ.get("FIXCA_BENCH_REHEARSE") == "1"
+    local = local % torch.cuda.device_count() if rehearse else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == max(1, args.gpus) or world == 1, "launch N>1 with torch.distributed.run"
 
     # rank 0 owns the parameters; everyone else receives them over RCCL
