@@ -19,5 +19,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1 || echo "pmc pass failed: $set" >> $OUT/errors.log
 done
-python3 $ROOT/tools/summarize_prof.py $OUT "k_roll<4>" $OUT/hbm_traffic.json > $OUT/summary.txt 2>&1 || true
+python3 $ROOT/tools/summarize_prof.py $OUT "k_roll<4" $OUT/hbm_traffic.json > $OUT/summary.txt 2>&1 || true
 cat $OUT/summary.txt

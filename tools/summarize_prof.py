@@ -23,7 +23,7 @@ def traffic_json(d, kernel_prefix, out_path):
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(os.path.join(d, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True):
             rows = [r for r in csv.DictReader(open(f))
-                    if short(r["Kernel_Name"]).startswith(kernel_prefix) and r["Counter_Name"] == name]
+                    if kernel_prefix in short(r["Kernel_Name"]) and r["Counter_Name"] == name]
             if rows:
                 # the batched launches only (largest grid): the same command also makes single-image calls
                 gmax = max(int(r["Grid_Size"]) for r in rows)
