@@ -72,7 +72,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
 #define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
 #define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
+#ifndef RDEPTH
 #define RDEPTH      6                   /* source rows kept in flight beyond the newest row in use */
+#endif
 #ifndef ROLL_LD_AUX
 #define ROLL_LD_AUX 0                   /* cache policy bits of the ring loads (2 = nt)           */
 #endif
@@ -494,11 +496,19 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	 * image k's last waves leave: no fill/drain bubble per image. */
 	const int img = blockIdx.x / pl.nblocks;
 	const int lane = threadIdx.x;
-	const int tile = xcd_remap(blockIdx.x - img * pl.nblocks, pl.nblocks);
+	const int bid = blockIdx.x - img * pl.nblocks;
+	int tile = xcd_remap(bid, pl.nblocks);
+#if defined(FIXCA_EXP_ORDER)                    /* timing experiment: tile order */
+	if (pl.ablate == 1) tile = bid;                                  /* consecutive tiles on different XCDs */
+#endif
 	if (tile >= pl.nwaves) return;
 	const uint8_t *__restrict__ src = imgs.src[img];
 	uint8_t *__restrict__ dst = imgs.dst[img];
-	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
+	int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
+#if defined(FIXCA_EXP_ORDER)
+	if (pl.ablate == 2) { chunk = tile % pl.nchunks; strip = tile / pl.nchunks; }          /* strip-major within the XCD range */
+	if (pl.ablate == 3) { tile = bid; chunk = tile % pl.nchunks; strip = tile / pl.nchunks; }
+#endif
 	const int W = g.W, H = g.H, oc = pl.oc;
 	const int X0 = strip * oc;                      /* the last strip may be narrower: its extra lanes store nothing */
 	const int Y0 = g.y1 + chunk * pl.th;

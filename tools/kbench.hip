@@ -66,6 +66,35 @@ __global__ __launch_bounds__(256) void strip_copy(const uint8_t *__restrict__ sr
 	}
 }
 
+// ---- the same tile pattern without LDS: global_load -> registers (D rows in flight) -> global_store -------
+template <int D, bool NT>
+__global__ __launch_bounds__(256) void strip_direct(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves)
+{
+	const int lane = threadIdx.x & 63;
+	const int wib = threadIdx.x >> 6;
+	const int wid = blockIdx.x * 4 + wib;
+	if (wid >= nwaves) return;
+	const int strip = wid % nstrips, chunk = wid / nstrips;
+	int X0 = strip * 256; if (X0 > W - 256) X0 = W - 256;
+	const int Y0 = chunk * th, Y1 = min(Y0 + th, H);
+	const size_t pitch = (size_t)W * 4;
+	const uint8_t *g = src + (size_t)Y0 * pitch + (size_t)(X0 + 4 * lane) * 4;
+	uint8_t *o = dst + (size_t)Y0 * pitch + (size_t)(X0 + 4 * lane) * 4;
+	u32x4 buf[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) if (Y0 + d < Y1) buf[d] = NT ? __builtin_nontemporal_load((const u32x4 *)(g + d * pitch)) : *(const u32x4 *)(g + d * pitch);
+	for (int y = Y0; y < Y1; y += D) {
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			if (y + d < Y1) {
+				u32x4 v = buf[d];
+				if (y + d + D < Y1) buf[d] = NT ? __builtin_nontemporal_load((const u32x4 *)(g + (size_t)(y - Y0 + d + D) * pitch)) : *(const u32x4 *)(g + (size_t)(y - Y0 + d + D) * pitch);
+				__builtin_nontemporal_store(v, (u32x4 *)(o + (size_t)(y - Y0 + d) * pitch));
+			}
+		}
+	}
+}
+
 template <typename F>
 static double time_it(int launches, F f)
 {
@@ -116,6 +145,16 @@ int main(int argc, char **argv)
 			snprintf(nm, 96, "strip_copy th=%d K=%d D=%d nt=%d waves=%d", th, K, D, (int)NTS, nwaves); \
 			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_copy<D, NTS>), dim3(nb), dim3(256), lds, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips, nwaves, K); })); }
 			SK(2, false) SK(4, false) SK(7, false) SK(4, true) SK(7, true)
+		}
+	}
+
+	if (!getenv("KB_SKIP_SKEL")) {
+		for (int th : {16, 32, 64}) {
+			int nstrips = (W + 255) / 256, nchunks = (H + th - 1) / th, nwaves = nstrips * nchunks, nb = (nwaves + 3) / 4;
+			char nm[96];
+#define SD(D, NT) { snprintf(nm, 96, "strip_direct th=%d D=%d ntload=%d waves=%d", th, D, (int)NT, nwaves); \
+			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_direct<D, NT>), dim3(nb), dim3(256), 0, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips, nwaves); })); }
+			SD(4, false) SD(8, false) SD(8, true)
 		}
 	}
 
