@@ -299,12 +299,12 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 			m[c] = mn;
 		}
 		int U0 = lo & ~ROLL_U0_MASK;
-		if (U0 > W - FIXCA_WAVE_COLS) U0 = W - FIXCA_WAVE_COLS;
-		if (hi > U0 + FIXCA_WAVE_COLS - 1) return false;
+		if (U0 > W - ROLL_WIN) U0 = W - ROLL_WIN;
+		if (hi > U0 + ROLL_WIN - 1) return false;
 		const int nact = (xe - X0) >> 2;                /* producing lanes; lane `nact` is read as a neighbour */
 		for (int c = 0; c < 2; ++c) {
 			const int P = X0 + m[c] - U0;
-			if (P < -4 || P + 4 * nact + 4 > FIXCA_WAVE_COLS + 16) return false;
+			if (P < -4 || P + 4 * nact + 4 > ROLL_WIN + 16) return false;
 		}
 	}
 	return true;
@@ -312,7 +312,7 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 
 static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 {
-	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < FIXCA_WAVE_COLS) return false;
+	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < ROLL_WIN) return false;
 	if ((long long)g->W * g->H * g->bpp > (1LL << 31)) return false;       /* 32-bit buffer offsets, see k_roll */
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
@@ -326,15 +326,16 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 	/* Strip width: a multiple of 16 pixels makes every row store start and end on a 64-byte
 	 * boundary (no memory line is shared by two waves' stores; measured 6 % faster than the
 	 * widest width that fits, 248); other widths only if no such width fits. */
-	const int oc_env = env_int("FIXCA_OC", 0, 0, 252) & ~3;
+	const int oc_top = (ROLL_WIN > 256) ? 256 : 252;
+	const int oc_env = env_int("FIXCA_OC", 0, 0, oc_top) & ~3;
 	int oc_pick = 0;
 	if (oc_env) {
 		for (int oc = oc_env; oc >= 128 && !oc_pick; oc -= 4)
 			if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
 	} else {
-		for (int oc = 240; oc >= 128 && !oc_pick; oc -= 16)
+		for (int oc = oc_top & ~15; oc >= 128 && !oc_pick; oc -= 16)
 			if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
-		for (int oc = 252; oc >= 128 && !oc_pick; oc -= 4)
+		for (int oc = oc_top; oc >= 128 && !oc_pick; oc -= 4)
 			if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
 	}
 	for (int oc = oc_pick; oc >= 128; oc = 0) {
@@ -351,7 +352,7 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 		 * first window); a row time grows with the k = ceil(waves / 256) waves sharing a CU about
 		 * as 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9): mostly latency, partly
 		 * throughput. */
-		int per_cu = (160 * 1024) / (ring * 256 * g->bpp + 512);
+		int per_cu = (160 * 1024) / (ring * ROLL_WIN * g->bpp + 512);
 		if (per_cu > 7) per_cu = 7;                     /* measured: 7 waves per CU beat 8 and 9 at equal total rows */
 		int best_th = 0;
 		long best_cost = 0;

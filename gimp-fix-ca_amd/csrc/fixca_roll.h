@@ -10,6 +10,16 @@
 
 /* the 256-column source window of a strip starts on a multiple of (ROLL_U0_MASK + 1) pixels:
  * 4 pixels = 16 bytes is what the LDS-DMA and the 16-byte LDS reads need */
+/* columns of a strip's source window held in a ring row.  256: one 16-byte-per-lane LDS-DMA per
+ * row, the last lane's neighbour pixels come over a DPP wave shift, strips up to 248 columns.
+ * 272: a second, 4-lane DMA adds 16 columns, every lane reads its 8 pixels itself, strips of 256
+ * columns (full 1 KB row stores, 64 producing lanes).  Measured on 6000x4000 cubic: 272 is 4 %
+ * slower (36.65 vs 35.1 us per image; the extra DMA and window reads cost more than the wider
+ * strips save), so 256 is the default and 272 a build option (-DROLL_WIN=272). */
+#ifndef ROLL_WIN
+#define ROLL_WIN 256
+#endif
+
 #ifndef ROLL_U0_MASK
 #define ROLL_U0_MASK 3
 #endif

@@ -67,7 +67,7 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define k_roll_tables k_roll_tables_rgb
 #endif
 
-#define RING_ROW    (256 * ROLL_BPP)    /* bytes per ring row: 256 px                             */
+#define RING_ROW    (ROLL_WIN * ROLL_BPP)   /* bytes per ring row                                  */
 
 namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
 #define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
@@ -147,6 +147,7 @@ struct RollState {
 	unsigned long long last, acc[8];
 #endif
 	static constexpr int T = TAPS;
+	int      lane;
 	int      tap[2];            /* byte offset (may be negative) of my 4-pixel window in a ring row */
 	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
 	/* ring */
@@ -183,18 +184,27 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
 	const int slot = roll_slot(st, st.ld);
 #if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
 #if ROLL_BPP == 4
-	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)(st.ring + slot * RING_ROW),
-	                                         16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
+	__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(st.ring + slot * RING_ROW);
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
+#if ROLL_WIN > 256
+	/* columns 256 .. 271 of the window: 4 lanes x 16 bytes (the instruction offset applies to
+	 * the global and to the LDS address alike) */
+	if (st.lane < (ROLL_WIN - 256) / 4)
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 16, st.vo_ld, st.so_ld, 1024, ROLL_LD_AUX);
+#endif
 #else
 	/* A 12-byte LDS-DMA puts lane L's bytes at 16 L (a 4-byte hole after every 4 pixels), so the
 	 * 768-byte row segment is moved as three 256-byte pieces of one dword per lane instead: the
 	 * ring row stays contiguous.  (The instruction offset applies to the global AND the LDS
-	 * address, so all three use the same LDS base.)  Three loads per row: roll_fetch counts
-	 * accordingly. */
+	 * address, so all pieces use the same LDS base.) */
 	__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(st.ring + slot * RING_ROW);
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 256, ROLL_LD_AUX);
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 512, ROLL_LD_AUX);
+#if ROLL_WIN > 256
+	if (st.lane < (ROLL_WIN - 256) * 3 / 4)          /* columns 256 .. 271: 48 bytes */
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 768, ROLL_LD_AUX);
+#endif
 #endif
 #endif
 	st.so_ld += st.pitch;
@@ -217,7 +227,7 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
 #if defined(FIXCA_EXP_NOVMWAIT)                 /* timing experiment only: reads rows that may not have landed */
 	return;
 #endif
-	constexpr int LPR = (ROLL_BPP == 4) ? 1 : 3;     /* loads per row */
+	constexpr int LPR = ((ROLL_BPP == 4) ? 1 : 3) + ((ROLL_WIN > 256) ? 1 : 0);     /* loads per row */
 	const int younger = st.ld - need;
 	if (younger >= 8) roll_wait_vm<8 * LPR>();
 	else if (younger >= 6) roll_wait_vm<6 * LPR>();
@@ -274,9 +284,11 @@ __device__ __forceinline__ uint32_t next_lane_dword(uint32_t v)
 __device__ __forceinline__ float ubyte_f32(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 #endif
 
-/* the 8 (NP used) pixels of my window of one source row per channel, as (red, blue) floats */
+/* the 8 (NP used) pixels of my window of one source row per channel, as (red, blue) floats.
+ * pr / pb: my 4 pixels; with the 272-column window every lane has also read the next 4 (nr / nb),
+ * with the 256-column window they come from lane L + 1 over DPP. */
 template <int NP>
-__device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, f32x2 (&tp)[NP])
+__device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, const u32x4 &nr, const u32x4 &nb, f32x2 (&tp)[NP])
 {
 #if ROLL_BPP == 4
 #pragma unroll
@@ -284,19 +296,38 @@ __device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, f32x2
 		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
 #pragma unroll
 	for (int k = 4; k < NP; ++k)
+#if ROLL_WIN > 256
+		tp[k] = f32x2{ (float)(nr[k - 4] & 0xffu), (float)((nb[k - 4] >> 16) & 0xffu) };
+#else
 		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
+#endif
 #else
 	/* 12 bytes [R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3]: red of pixel k is byte 3k, blue byte 3k + 2 */
 	tp[0] = f32x2{ ubyte_f32(pr[0], 0), ubyte_f32(pb[0], 2) };
 	tp[1] = f32x2{ ubyte_f32(pr[0], 3), ubyte_f32(pb[1], 1) };
 	tp[2] = f32x2{ ubyte_f32(pr[1], 2), ubyte_f32(pb[2], 0) };
 	tp[3] = f32x2{ ubyte_f32(pr[2], 1), ubyte_f32(pb[2], 3) };
+#if ROLL_WIN > 256
+	const uint32_t nr0 = nr[0], nr1 = nr[1], nr2 = nr[2], nb0 = nb[0], nb1 = nb[1], nb2 = nb[2];
+#else
 	const uint32_t nr0 = next_lane_dword(pr[0]), nr1 = next_lane_dword(pr[1]), nr2 = next_lane_dword(pr[2]);
 	const uint32_t nb0 = next_lane_dword(pb[0]), nb1 = next_lane_dword(pb[1]), nb2 = next_lane_dword(pb[2]);
+#endif
 	if (NP > 4) tp[4] = f32x2{ ubyte_f32(nr0, 0), ubyte_f32(nb0, 2) };
 	if (NP > 5) tp[5 < NP ? 5 : 0] = f32x2{ ubyte_f32(nr0, 3), ubyte_f32(nb1, 1) };
 	if (NP > 6) tp[6 < NP ? 6 : 0] = f32x2{ ubyte_f32(nr1, 2), ubyte_f32(nb2, 0) };
 	if (NP > 7) tp[7 < NP ? 7 : 0] = f32x2{ ubyte_f32(nr2, 1), ubyte_f32(nb2, 3) };
+#endif
+}
+
+/* the pixels after my 4-pixel tap window (272-column window only; a dummy otherwise) */
+template <int TAPS, bool P2>
+__device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2> &st, int row, int off)
+{
+#if ROLL_WIN > 256
+	return roll_ring_win(st, row, off + 4 * ROLL_BPP);
+#else
+	return u32x4{ 0u, 0u, 0u, 0u };
 #endif
 }
 
@@ -306,10 +337,10 @@ template <int TAPS, bool P2, int NW>
 __device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5],
                                           int rowR, int rowB, f32x2 (&h)[4])
 {
-	const u32x4 pr = roll_ring_win(st, rowR, st.tap[0]);
-	const u32x4 pb = roll_ring_win(st, rowB, st.tap[1]);
+	const u32x4 pr = roll_ring_win(st, rowR, st.tap[0]), nr = roll_ring_next(st, rowR, st.tap[0]);
+	const u32x4 pb = roll_ring_win(st, rowB, st.tap[1]), nb = roll_ring_next(st, rowB, st.tap[1]);
 	f32x2 tp[NW + 3];
-	roll_px8<NW + 3>(pr, pb, tp);
+	roll_px8<NW + 3>(pr, pb, nr, nb, tp);
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		f32x2 a = wx[i][0] * tp[i];
@@ -408,11 +439,13 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	STAMP(1);                                       /* fetch: DMA issue + wait */
 	const int nR = b.rb[0] + T - 1, nB = b.rb[1] + T - 1;   /* newest row of output row y */
 
-	u32x4 idt[NR], pr[NR], pb[NR];
+	u32x4 idt[NR], pr[NR], pb[NR], nr[NR], nb[NR];
 #pragma unroll
 	for (int n = 0; n < NR; ++n) {
 		pr[n] = roll_ring_win(st, nR + n, st.tap[0]);
+		nr[n] = roll_ring_next(st, nR + n, st.tap[0]);
 		pb[n] = roll_ring_win(st, nB + n, st.tap[1]);
+		nb[n] = roll_ring_next(st, nB + n, st.tap[1]);
 		idt[n] = roll_ring_px(st, y + n, st.my_idt);
 	}
 	f32x2 acc[NR][4], wy[NR][T];
@@ -446,7 +479,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
 #pragma unroll
-	for (int n = 0; n < NR; ++n) roll_px8<NP>(pr[n], pb[n], tp[n]);
+	for (int n = 0; n < NR; ++n) roll_px8<NP>(pr[n], pb[n], nr[n], nb[n], tp[n]);
 #pragma unroll
 	for (int t = 0; t < NW; ++t)
 #pragma unroll
@@ -515,6 +548,7 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	const int nrows = min(pl.th, g.y2 - Y0);
 
 	RollState<TAPS, P2> st;
+	st.lane = threadIdx.x;
 #if defined(FIXCA_EXP_STAMPS)
 	st.last = __builtin_amdgcn_s_memtime();
 	const unsigned long long t_begin = st.last;
@@ -569,8 +603,9 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	}
 	/* lanes past the last producing lane only serve as its DPP neighbour: they all read where
 	 * lane `nact` reads, so a narrow last strip never reads far outside its ring row */
-	st.tap[0] = (hd.tapR + 4 * min(lane, nact)) * ROLL_BPP;
-	st.tap[1] = (hd.tapB + 4 * min(lane, nact)) * ROLL_BPP;
+	constexpr int NB = (ROLL_WIN > 256) ? 1 : 0;     /* 256-column window: lane nact serves as lane nact-1's DPP neighbour */
+	st.tap[0] = (hd.tapR + 4 * min(lane, nact - NB)) * ROLL_BPP;
+	st.tap[1] = (hd.tapB + 4 * min(lane, nact - NB)) * ROLL_BPP;
 	st.my_idt = (uint32_t)((X0 - U0) + 4 * min(lane, nact - 1)) * ROLL_BPP;
 	/* a lane without output stores at offset `total`: past the end whether or not the range check
 	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
@@ -693,7 +728,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 		if constexpr (T == 1) lo = min(lo, map_int(X0, g.xc, W, g.s[c], g.xs[c]));
 		else lo = min(lo, rclampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1));
 	}
-	const int U0 = min(lo & ~ROLL_U0_MASK, W - FIXCA_WAVE_COLS);
+	const int U0 = min(lo & ~ROLL_U0_MASK, W - ROLL_WIN);
 
 	const int nact = min(oc, W - X0) >> 2;           /* lanes that produce output */
 	const bool active = lane < nact;
