@@ -66,6 +66,41 @@ __global__ __launch_bounds__(256) void strip_copy(const uint8_t *__restrict__ sr
 	}
 }
 
+// ---- LDS-ring skeleton with 512-column strips: two 1 KB DMAs and two 16-byte stores per lane and row ----
+template <int D>
+__global__ __launch_bounds__(256) void strip_copy_wide(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves, int K)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
+	const int lane = threadIdx.x & 63;
+	const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int wid = blockIdx.x * 4 + wib;
+	if (wid >= nwaves) return;
+	const int strip = wid % nstrips, chunk = wid / nstrips;
+	int X0 = strip * 512; if (X0 > W - 512) X0 = W - 512;
+	const int Y0 = chunk * th, Y1 = min(Y0 + th, H);
+	const size_t pitch = (size_t)W * 4;
+	uint8_t *myring = ring + (size_t)wib * K * 2048;
+	const uint32_t loff = (uint32_t)(X0 + 4 * lane) * 4;
+	auto issue = [&](int row) {
+		const uint8_t *g = src + (size_t)row * pitch + loff;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+			(__attribute__((address_space(3))) void *)(myring + (row % K) * 2048), 16, 0, 0);
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 1024),
+			(__attribute__((address_space(3))) void *)(myring + (row % K) * 2048 + 1024), 16, 0, 0);
+	};
+#pragma unroll
+	for (int d = 0; d < D; ++d) if (Y0 + d < Y1) issue(Y0 + d);
+	for (int y = Y0; y < Y1; ++y) {
+		if (y + D < Y1) issue(y + D);
+		wait_vm<4 * D>();
+		u32x4 v0 = *reinterpret_cast<const u32x4 *>(myring + (y % K) * 2048 + lane * 16);
+		u32x4 v1 = *reinterpret_cast<const u32x4 *>(myring + (y % K) * 2048 + 1024 + lane * 16);
+		u32x4 *o = reinterpret_cast<u32x4 *>(dst + (size_t)y * pitch + loff);
+		__builtin_nontemporal_store(v0, o);
+		__builtin_nontemporal_store(v1, o + 64);
+	}
+}
+
 // ---- the same tile pattern without LDS: global_load -> registers (D rows in flight) -> global_store -------
 template <int D, bool NT>
 __global__ __launch_bounds__(256) void strip_direct(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves)
@@ -155,6 +190,17 @@ int main(int argc, char **argv)
 #define SD(D, NT) { snprintf(nm, 96, "strip_direct th=%d D=%d ntload=%d waves=%d", th, D, (int)NT, nwaves); \
 			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_direct<D, NT>), dim3(nb), dim3(256), 0, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips, nwaves); })); }
 			SD(4, false) SD(8, false) SD(8, true)
+		}
+	}
+
+	if (!getenv("KB_SKIP_SKEL")) {
+		for (int th : {16, 32, 64}) for (int K : {8}) {
+			int nstrips = (W + 511) / 512, nchunks = (H + th - 1) / th, nwaves = nstrips * nchunks, nb = (nwaves + 3) / 4;
+			size_t lds = (size_t)4 * K * 2048;
+			char nm[96];
+			hipFuncSetAttribute((const void *)strip_copy_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			snprintf(nm, 96, "strip_copy_wide(512) th=%d K=%d D=4 waves=%d", th, K, nwaves);
+			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_copy_wide<4>), dim3(nb), dim3(256), lds, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips, nwaves, K); }));
 		}
 	}
 
