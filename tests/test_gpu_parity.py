@@ -357,6 +357,33 @@ def test_table_cache_across_geometries_and_streams(torch_cuda):
         assert mx <= TOL_LSB
 
 
+def test_batch_entry_replays_from_a_hip_graph(torch_cuda):
+    """the batch entry makes no allocation or synchronisation once its tables exist, so a caller
+    can capture it into a graph and replay it on new pixel data"""
+    torch = torch_cuda
+    w, h = 768, 90
+    p = fixca.make_params(blue=0.7, red=-0.5, lens_x=200, lens_y=33, interpolation=2, y_blue=1.25)
+    assert fixca.plan(w, h, 4, 1, p)[0] == 6
+    imgs = [synth.noise_image(300 + i, w, h, 4) for i in range(3)]
+    srcs = [torch.from_numpy(a).cuda() for a in imgs]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    fixca.fix_ca_batch(srcs, dsts, w, h, 4, 1, p)               # warm: builds the tables
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fixca.fix_ca_batch(srcs, dsts, w, h, 4, 1, p)
+    new = [synth.noise_image(400 + i, w, h, 4) for i in range(3)]
+    for s, a in zip(srcs, new):
+        s.copy_(torch.from_numpy(a))
+    for d in dsts:
+        d.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, d in zip(new, dsts):
+        mx, _ = diff_stats(d.cpu().numpy(), oracle_run(a, p))
+        assert mx <= TOL_LSB
+
+
 def test_batch_entry_more_images_than_one_launch_takes(torch_cuda):
     """the row-rolling kernel takes 32 images per launch: 70 images = 3 launches"""
     torch = torch_cuda

@@ -66,6 +66,38 @@ __global__ __launch_bounds__(256) void strip_copy(const uint8_t *__restrict__ sr
 	}
 }
 
+template <int D, bool NTS>
+__global__ __launch_bounds__(256) void strip_copy_sync(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves, int K)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
+	const int lane = threadIdx.x & 63;
+	const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int wid = blockIdx.x * 4 + wib;
+	const bool dead = wid >= nwaves;
+	const int widc = dead ? nwaves - 1 : wid;
+	const int strip = widc % nstrips, chunk = widc / nstrips;
+	int X0 = strip * 256; if (X0 > W - 256) X0 = W - 256;
+	const int Y0 = chunk * th, Y1 = min(Y0 + th, H);
+	const size_t pitch = (size_t)W * 4;
+	uint8_t *myring = ring + (size_t)wib * K * 1024;
+	const uint32_t loff = (uint32_t)(X0 + 4 * lane) * 4;
+	auto issue = [&](int row) {
+		const uint8_t *g = src + (size_t)row * pitch + loff;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+			(__attribute__((address_space(3))) void *)(myring + (row % K) * 1024), 16, 0, 0);
+	};
+#pragma unroll
+	for (int d = 0; d < D; ++d) if (Y0 + d < Y1) issue(Y0 + d);
+	for (int y = Y0; y < Y1; ++y) {
+		if (y + D < Y1) issue(y + D);
+		wait_vm<2 * D>();
+		__builtin_amdgcn_s_barrier();            /* the 4 waves of the workgroup (4 adjacent strips) stay on the same row */
+		u32x4 v = *reinterpret_cast<const u32x4 *>(myring + (y % K) * 1024 + lane * 16);
+		u32x4 *o = reinterpret_cast<u32x4 *>(dst + (size_t)y * pitch + loff);
+		if (NTS) __builtin_nontemporal_store(v, o); else *o = v;
+	}
+}
+
 // ---- LDS-ring skeleton with 512-column strips: two 1 KB DMAs and two 16-byte stores per lane and row ----
 template <int D>
 __global__ __launch_bounds__(256) void strip_copy_wide(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves, int K)
@@ -193,6 +225,19 @@ int main(int argc, char **argv)
 		}
 	}
 
+	if (!getenv("KB_SKIP_SKEL")) {
+		for (int th : {16, 32}) {
+			const int K = 16;
+			int nstrips = (W + 255) / 256, nchunks = (H + th - 1) / th;
+			// strips padded to a multiple of 4 so that a workgroup's 4 waves share a chunk
+			int nstrips4 = (nstrips + 3) & ~3, nwaves = nstrips4 * nchunks, nb = nwaves / 4;
+			size_t lds = (size_t)4 * K * 1024;
+			char nm[96];
+			hipFuncSetAttribute((const void *)strip_copy_sync<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			snprintf(nm, 96, "strip_copy_sync th=%d K=16 D=7 nt=1 waves=%d", th, nwaves);
+			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_copy_sync<7, true>), dim3(nb), dim3(256), lds, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips4, nwaves, K); }));
+		}
+	}
 	if (!getenv("KB_SKIP_SKEL")) {
 		for (int th : {16, 32, 64}) for (int K : {8}) {
 			int nstrips = (W + 511) / 512, nchunks = (H + th - 1) / th, nwaves = nstrips * nchunks, nb = (nwaves + 3) / 4;
