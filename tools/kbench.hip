@@ -204,14 +204,14 @@ int main(int argc, char **argv)
 
 
 	if (!getenv("KB_SKIP_SKEL")) {
-		for (int th : {16, 32, 64}) for (int K : {8, 16}) {
+		for (int th : {16, 32, 64}) for (int K : {8, 16, 32}) {
 			int nstrips = (W + 255) / 256, nchunks = (H + th - 1) / th, nwaves = nstrips * nchunks, nb = (nwaves + 3) / 4;
 			size_t lds = (size_t)4 * K * 1024;
 			char nm[96];
 #define SK(D, NTS) if (D < K) { hipFuncSetAttribute((const void *)strip_copy<D, NTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 			snprintf(nm, 96, "strip_copy th=%d K=%d D=%d nt=%d waves=%d", th, K, D, (int)NTS, nwaves); \
 			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_copy<D, NTS>), dim3(nb), dim3(256), lds, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips, nwaves, K); })); }
-			SK(2, false) SK(4, false) SK(7, false) SK(4, true) SK(7, true)
+			SK(2, false) SK(4, false) SK(7, false) SK(4, true) SK(7, true) SK(14, true) SK(24, true)
 		}
 	}
 
