@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "gimp-fix-ca_amd"))
 
 W, H, C = 6000, 4000, 4
 PARAMS = dict(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=2)
+METRIC = "Mpixels/s lateral-CA cubic on 6000\u00d74000 RGBA; % of HBM-read roofline"     # BASELINE.json's metric
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = 2 * C        # every source byte read once, every result byte written once
 
@@ -180,7 +181,7 @@ def main():
             # recorded per launch of the profiled run; scaled if this run batches differently
             traffic = round(t.get("bytes_per_launch") * imgs_per_launch / max(1, t.get("images_per_launch", 1)))
         out = {
-            "metric": "Mpixels/s lateral-CA cubic on 6000x4000 RGBA",
+            "metric": METRIC,
             "value": round(world * args.steps * B * W * H / wall / 1e6, 1),
             "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

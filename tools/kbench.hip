@@ -98,6 +98,38 @@ __global__ __launch_bounds__(256) void strip_copy_sync(const uint8_t *__restrict
 	}
 }
 
+// ---- LDS-ring skeleton, one strip per 4-wave workgroup: wave w copies the rows y = w (mod 4) of the chunk,
+// so a quarter as many row streams are in flight, each four times as fast ----------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void strip_copy_wg(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int ntiles, int K)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
+	const int lane = threadIdx.x & 63;
+	const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int tile = blockIdx.x;
+	if (tile >= ntiles) return;
+	const int strip = tile % nstrips, chunk = tile / nstrips;
+	int X0 = strip * 256; if (X0 > W - 256) X0 = W - 256;
+	const int Y0 = chunk * th, Y1 = min(Y0 + th, H);
+	const size_t pitch = (size_t)W * 4;
+	uint8_t *myring = ring + (size_t)wib * K * 1024;
+	const uint32_t loff = (uint32_t)(X0 + 4 * lane) * 4;
+	auto issue = [&](int row) {
+		const uint8_t *g = src + (size_t)row * pitch + loff;
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+			(__attribute__((address_space(3))) void *)(myring + ((row >> 2) % K) * 1024), 16, 0, 0);
+	};
+#pragma unroll
+	for (int d = 0; d < D; ++d) if (Y0 + wib + 4 * d < Y1) issue(Y0 + wib + 4 * d);
+	for (int y = Y0 + wib; y < Y1; y += 4) {
+		if (y + 4 * D < Y1) issue(y + 4 * D);
+		wait_vm<2 * D>();
+		u32x4 v = *reinterpret_cast<const u32x4 *>(myring + ((y >> 2) % K) * 1024 + lane * 16);
+		u32x4 *o = reinterpret_cast<u32x4 *>(dst + (size_t)y * pitch + loff);
+		__builtin_nontemporal_store(v, o);
+	}
+}
+
 // ---- LDS-ring skeleton with 512-column strips: two 1 KB DMAs and two 16-byte stores per lane and row ----
 template <int D>
 __global__ __launch_bounds__(256) void strip_copy_wide(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves, int K)
@@ -225,6 +257,17 @@ int main(int argc, char **argv)
 		}
 	}
 
+	if (!getenv("KB_SKIP_SKEL")) {
+		for (int th : {64, 128, 256}) {
+			const int K = 16;
+			int nstrips = (W + 255) / 256, nchunks = (H + th - 1) / th, ntiles = nstrips * nchunks;
+			size_t lds = (size_t)4 * K * 1024;
+			char nm[96];
+			hipFuncSetAttribute((const void *)strip_copy_wg<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			snprintf(nm, 96, "strip_copy_wg th=%d K=16 D=7 workgroups=%d", th, ntiles);
+			report(nm, time_it(L, [&](int i) { hipLaunchKernelGGL((strip_copy_wg<7>), dim3(ntiles), dim3(256), lds, 0, (const uint8_t *)src4[i % NP], (uint8_t *)dst4[i % NP], W, H, th, nstrips, ntiles, K); }));
+		}
+	}
 	if (!getenv("KB_SKIP_SKEL")) {
 		for (int th : {16, 32}) {
 			const int K = 16;
