@@ -163,6 +163,16 @@ def main():
             t = time.perf_counter()
             fixca.fix_ca_region(hsrc, hdst, W, H, C, 1, params, 0, W, 0, H, True)
             extra["host_entry_pcie_inclusive_mpix_s"] = round(W * H / (time.perf_counter() - t) / 1e6, 1)
+            # the same call on page-locked buffers (fixca_host_alloc), as INTEGRATION.md suggests for fix_ca()
+            psrc, pdst = fixca.pinned_empty(hsrc.shape), fixca.pinned_empty(hsrc.shape)
+            psrc[...] = hsrc
+            fixca.fix_ca_region(psrc, pdst, W, H, C, 1, params, 0, W, 0, H, True)
+            t = time.perf_counter()
+            fixca.fix_ca_region(psrc, pdst, W, H, C, 1, params, 0, W, 0, H, True)
+            extra["host_entry_pinned_pcie_inclusive_mpix_s"] = round(W * H / (time.perf_counter() - t) / 1e6, 1)
+            ok = ok and bool(np.array_equal(pdst, hdst))
+            fixca.pinned_free(psrc)
+            fixca.pinned_free(pdst)
             fixca.lib.fixca_release_cache()
     ok = fdist.all_ranks_ok(ok, device=dev)
 

@@ -4,6 +4,7 @@
  * is no CPU fallback.
  */
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -76,6 +77,23 @@ extern "C" void *fixca_dev_alloc(size_t nbytes)
 extern "C" int fixca_dev_free(void *p)
 {
 	HIP_TRY(hipFree(p));
+	return FIXCA_OK;
+}
+
+extern "C" void *fixca_host_alloc(size_t nbytes)
+{
+	void *p = NULL;
+	hipError_t e = hipHostMalloc(&p, nbytes ? nbytes : 1, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		fixca_fail(FIXCA_E_HIP, "hipHostMalloc(%zu): %s", nbytes, hipGetErrorString(e));
+		return NULL;
+	}
+	return p;
+}
+
+extern "C" int fixca_host_free(void *p)
+{
+	HIP_TRY(hipHostFree(p));
 	return FIXCA_OK;
 }
 
@@ -181,6 +199,55 @@ extern "C" void fixca_release_cache(void)
 	g_cache_bytes = 0;
 }
 
+/* rows above / below an output row that its taps can reach: |y' - y| <= |s - 1| * (distance of the
+ * farthest row from the centre) + |shift|, plus the cubic window */
+static int vertical_reach(const FixcaGeom *g)
+{
+	double r = 0.0;
+	for (int c = 0; c < 2; ++c) {
+		const double far = fmax(fabs(0.0 - (double)g->yc), fabs((double)(g->H - 1) - (double)g->yc));
+		const double d = fabs(g->s[c] - 1.0) * far + fabs(g->ys[c]);
+		if (d > r) r = d;
+	}
+	if (!(r < (double)g->H)) return g->H;
+	return (int)ceil(r) + 3;
+}
+
+static bool is_pinned(const void *p)
+{
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+		(void)hipGetLastError();                 /* an ordinary malloc'ed pointer is "invalid value" here */
+		return false;
+	}
+	return a.type == hipMemoryTypeHost;
+}
+
+/* streams and events of the host entry's upload / compute / download pipeline */
+namespace {
+constexpr int PIPE_BANDS = 8;
+struct Pipe {
+	bool        ready = false;
+	hipStream_t up = nullptr, run = nullptr, down = nullptr;
+	hipEvent_t  uploaded[PIPE_BANDS], done[PIPE_BANDS];
+};
+thread_local Pipe g_pipe;
+}
+
+static int pipe_init(void)
+{
+	if (g_pipe.ready) return FIXCA_OK;
+	HIP_TRY(hipStreamCreateWithFlags(&g_pipe.up, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&g_pipe.run, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&g_pipe.down, hipStreamNonBlocking));
+	for (int i = 0; i < PIPE_BANDS; ++i) {
+		HIP_TRY(hipEventCreateWithFlags(&g_pipe.uploaded[i], hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&g_pipe.done[i], hipEventDisableTiming));
+	}
+	g_pipe.ready = true;
+	return FIXCA_OK;
+}
+
 extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, int W, int H, int bytes,
                                  int bpc, const FixCaParams *params, int x1, int x2, int y1, int y2,
                                  int show_progress)
@@ -191,6 +258,7 @@ extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, i
 	if (rc) return rc;                       /* argument errors are reported without touching the GPU */
 	rc = require_device();
 	if (rc) return rc;
+	if (y2 <= y1) return FIXCA_OK;
 
 	const size_t pitch = (size_t)W * bytes, total = pitch * H;
 	if (total > g_cache_bytes) {
@@ -201,15 +269,57 @@ extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, i
 	}
 	const char *ex = getenv("FIXCA_EXACT");
 	const unsigned flags = (ex && *ex && strcmp(ex, "0") != 0) ? FIXCA_KERNEL_EXACT : FIXCA_KERNEL_AUTO;
+	char *const d_src = static_cast<char *>(g_cache[0]);
+	char *const d_dst = static_cast<char *>(g_cache[1]);
 
-	HIP_TRY(hipMemcpy(g_cache[0], src, total, hipMemcpyHostToDevice));
-	rc = fixca_region_device(g_cache[0], g_cache[1], W, H, bytes, bpc, params, x1, x2, y1, y2,
-	                         show_progress, flags, NULL);
+	/* only the source rows the requested rows can reach are uploaded (the preview asks for a
+	 * window of rows, fix-ca.c:656) */
+	const int reach = vertical_reach(&g);
+	const int lo = y1 - reach > 0 ? y1 - reach : 0;
+	const int hi = y2 + reach < H ? y2 + reach : H;
+	const int rows = y2 - y1;
+
+	const char *np = getenv("FIXCA_NO_PIPELINE");
+	if (rows < 256 || (np && *np && strcmp(np, "0") != 0) || !is_pinned(src) || !is_pinned(dst)) {
+		HIP_TRY(hipMemcpy(d_src + (size_t)lo * pitch, src + (size_t)lo * pitch, (size_t)(hi - lo) * pitch, hipMemcpyHostToDevice));
+		rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, flags, NULL);
+		if (rc) return rc;
+		HIP_TRY(hipMemcpy(dst + (size_t)y1 * pitch, d_dst + (size_t)y1 * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost));
+		HIP_TRY(hipDeviceSynchronize());
+		return FIXCA_OK;
+	}
+
+	/* Page-locked buffers (fixca_host_alloc): upload, kernel and download of consecutive row
+	 * bands overlap on three streams, so the call takes about one transfer instead of two plus
+	 * the kernel (PCIe is full duplex). */
+	rc = pipe_init();
 	if (rc) return rc;
-	if (y2 > y1)
-		HIP_TRY(hipMemcpy(dst + (size_t)y1 * pitch, (const char *)g_cache[1] + (size_t)y1 * pitch,
-		                  (size_t)(y2 - y1) * pitch, hipMemcpyDeviceToHost));
-	HIP_TRY(hipDeviceSynchronize());
+	int bh = (rows + PIPE_BANDS - 1) / PIPE_BANDS;
+	bh = (bh + 3) & ~3;
+	int up_to = lo, band = 0;
+	for (int yb = y1; yb < y2; yb += bh, ++band) {
+		const int ye = yb + bh < y2 ? yb + bh : y2;
+		const int need_hi = ye + reach < H ? ye + reach : H;
+		if (need_hi > up_to) {
+			HIP_TRY(hipMemcpyAsync(d_src + (size_t)up_to * pitch, src + (size_t)up_to * pitch,
+			                       (size_t)(need_hi - up_to) * pitch, hipMemcpyHostToDevice, g_pipe.up));
+			up_to = need_hi;
+		}
+		HIP_TRY(hipEventRecord(g_pipe.uploaded[band], g_pipe.up));
+		HIP_TRY(hipStreamWaitEvent(g_pipe.run, g_pipe.uploaded[band], 0));
+		rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, x1, x2, yb, ye, show_progress, flags, g_pipe.run);
+		if (rc) {
+			(void)hipDeviceSynchronize();
+			return rc;
+		}
+		HIP_TRY(hipEventRecord(g_pipe.done[band], g_pipe.run));
+		HIP_TRY(hipStreamWaitEvent(g_pipe.down, g_pipe.done[band], 0));
+		HIP_TRY(hipMemcpyAsync(dst + (size_t)yb * pitch, d_dst + (size_t)yb * pitch, (size_t)(ye - yb) * pitch,
+		                       hipMemcpyDeviceToHost, g_pipe.down));
+	}
+	HIP_TRY(hipStreamSynchronize(g_pipe.down));
+	HIP_TRY(hipStreamSynchronize(g_pipe.run));
+	HIP_TRY(hipStreamSynchronize(g_pipe.up));
 	return FIXCA_OK;
 }
 

@@ -328,15 +328,30 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 	 * widest width that fits, 248); other widths only if no such width fits. */
 	const int oc_top = (ROLL_WIN > 256) ? 256 : 252;
 	const int oc_env = env_int("FIXCA_OC", 0, 0, oc_top) & ~3;
+	/* the width search walks every column for every candidate width and does not depend on the
+	 * row range: remembered per thread, so that a caller working through an image in row bands
+	 * (fixca_region_host's pipeline, the preview) plans each band in microseconds */
+	static thread_local struct { bool valid; FixcaGeom g; int oc_env; int oc_pick; } memo;
+	FixcaGeom key = *g;
+	key.y1 = key.y2 = 0;
+	key.preview = 0;
 	int oc_pick = 0;
-	if (oc_env) {
-		for (int oc = oc_env; oc >= 128 && !oc_pick; oc -= 4)
-			if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+	if (memo.valid && memo.oc_env == oc_env && memcmp(&memo.g, &key, sizeof key) == 0) {
+		oc_pick = memo.oc_pick;
 	} else {
-		for (int oc = oc_top & ~15; oc >= 128 && !oc_pick; oc -= 16)
-			if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
-		for (int oc = oc_top; oc >= 128 && !oc_pick; oc -= 4)
-			if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+		if (oc_env) {
+			for (int oc = oc_env; oc >= 128 && !oc_pick; oc -= 4)
+				if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+		} else {
+			for (int oc = oc_top & ~15; oc >= 128 && !oc_pick; oc -= 16)
+				if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+			for (int oc = oc_top; oc >= 128 && !oc_pick; oc -= 4)
+				if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+		}
+		memo.valid = true;
+		memo.g = key;
+		memo.oc_env = oc_env;
+		memo.oc_pick = oc_pick;
 	}
 	for (int oc = oc_pick; oc >= 128; oc = 0) {
 		const int rows = g->y2 - g->y1;

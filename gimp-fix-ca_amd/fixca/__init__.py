@@ -85,6 +85,8 @@ def _load():
         "fixca_set_device": ([ci], ci),
         "fixca_dev_alloc": ([ctypes.c_size_t], vp),
         "fixca_dev_free": ([vp], ci),
+        "fixca_host_alloc": ([ctypes.c_size_t], vp),
+        "fixca_host_free": ([vp], ci),
         "fixca_copy_h2d": ([vp, vp, ctypes.c_size_t, vp], ci),
         "fixca_copy_d2h": ([vp, vp, ctypes.c_size_t, vp], ci),
         "fixca_stream_sync": ([vp], ci),
@@ -207,6 +209,21 @@ def time_copy(srcs, dsts, launches, nbytes):
     _check(lib.fixca_time_copy(_ptr_array(srcs), _ptr_array(dsts), len(srcs), launches, nbytes,
                                _current_stream(), ctypes.byref(ms)))
     return ms.value
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array on page-locked host memory (fixca_host_alloc); free with pinned_free(arr)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib.fixca_host_alloc(n)
+    if not ptr:
+        raise FixCaError(E_HIP, lib.fixca_last_error().decode("utf-8", "replace"))
+    buf = (ctypes.c_uint8 * n).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    return arr
+
+
+def pinned_free(arr):
+    _check(lib.fixca_host_free(ctypes.c_void_p(arr.ctypes.data)))
 
 
 def device_count():

@@ -105,6 +105,14 @@ FIXCA_API int   fixca_dev_free(void *d_ptr);
 FIXCA_API int   fixca_copy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 FIXCA_API int   fixca_copy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
 FIXCA_API int   fixca_stream_sync(void *stream);
+/*
+ * Page-locked host memory for the two images fix_ca() allocates (g_new at fix-ca.c:366-367):
+ * gegl_buffer_get / gegl_buffer_set then work directly on memory the GPU's DMA engines can reach,
+ * and fixca_region_host's copies run at PCIe speed instead of through a staging buffer.
+ * Ordinary malloc'ed buffers keep working; these are an optimisation.
+ */
+FIXCA_API void *fixca_host_alloc(size_t nbytes);       /* NULL on failure              */
+FIXCA_API int   fixca_host_free(void *h_ptr);
 FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_host's buffers and the kernel tables */
 
 /* ---- timing on the launch stream (bench.py's roofline leg) -------------- */
