@@ -33,6 +33,13 @@ static int read_token(FILE *f, char *buf, int n)
 	return 1;
 }
 
+static int pixels_pinned;
+
+static void release_pixels(unsigned char *px)
+{
+	if (pixels_pinned) fixca_host_free(px); else free(px);
+}
+
 static unsigned char *read_image(const char *path, int *w, int *h, int *bpp)
 {
 	char tok[64];
@@ -65,8 +72,10 @@ static unsigned char *read_image(const char *path, int *w, int *h, int *bpp)
 		*bpp = 4;
 	} else goto done;
 	if (*w <= 0 || *h <= 0) goto done;
-	px = malloc((size_t)*w * *h * *bpp);
-	if (px && fread(px, (size_t)*w * *bpp, *h, f) != (size_t)*h) { free(px); px = NULL; }
+	px = fixca_host_alloc((size_t)*w * *h * *bpp);      /* page-locked: see fixca_host.c */
+	pixels_pinned = px != NULL;
+	if (!px) px = malloc((size_t)*w * *h * *bpp);       /* no GPU: fix_ca() reports it */
+	if (px && fread(px, (size_t)*w * *bpp, *h, f) != (size_t)*h) { release_pixels(px); px = NULL; }
 done:
 	fclose(f);
 	return px;
@@ -117,6 +126,6 @@ int main(int argc, char **argv)
 	d.sel_x = 0; d.sel_y = 0; d.sel_w = d.width; d.sel_h = d.height;
 	if (fix_ca(&d, &p)) return 1;
 	if (write_image(pos[1], d.pixels, d.width, d.height, d.bpp)) { fprintf(stderr, "cannot write %s\n", pos[1]); return 1; }
-	free(d.pixels);
+	release_pixels(d.pixels);
 	return 0;
 }

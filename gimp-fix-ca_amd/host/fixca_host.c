@@ -43,6 +43,7 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 {
 	unsigned char *dest;
 	size_t total;
+	int pinned;
 
 	if (!d || !d->pixels || !params) return -1;
 	if (d->sel_w <= 0 || d->sel_h <= 0) return -1;          /* mask_intersect failed (fix-ca.c:340) */
@@ -51,7 +52,11 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 		return -1;
 	}
 	total = (size_t)d->width * d->height * d->bpp;
-	dest = malloc(total);
+	/* page-locked like the reference's g_new'ed destImg would be with fixca_host_alloc:
+	 * with a page-locked source too, fixca_region_host pipelines upload, kernel and download */
+	dest = fixca_host_alloc(total);
+	pinned = dest != NULL;
+	if (!dest) dest = malloc(total);                        /* no GPU: the call below reports it */
 	if (!dest) return -1;
 
 	/* The reference passes the selection rectangle (fix-ca.c:373-374) although only
@@ -60,14 +65,14 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 	fix_ca_region(d->pixels, dest, d->width, d->height, d->bpp, d->bpc, params,
 	              d->sel_x, d->sel_x + d->sel_w, d->sel_y, d->sel_y + d->sel_h, 1);
 	if (fixca_host_status != FIXCA_OK) {
-		free(dest);
+		if (pinned) fixca_host_free(dest); else free(dest);
 		return -1;
 	}
 	/* gegl_buffer_set of the rectangle + merge_shadow (fix-ca.c:376-385) */
 	memcpy(d->pixels + (size_t)d->sel_y * d->width * d->bpp,
 	       dest + (size_t)d->sel_y * d->width * d->bpp,
 	       (size_t)d->sel_h * d->width * d->bpp);
-	free(dest);
+	if (pinned) fixca_host_free(dest); else free(dest);
 	return 0;
 }
 
