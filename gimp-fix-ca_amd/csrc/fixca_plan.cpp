@@ -316,7 +316,6 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 	if ((long long)g->W * g->H * g->bpp > (1LL << 31)) return false;       /* 32-bit buffer offsets, see k_roll */
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
-	/* a block of 4 output rows keeps span + 3 rows alive; leave >= 2 slots for rows in flight */
 	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that
 	 * fits (row mod 16 is one instruction); otherwise as small as 6 rows in flight allow, because
 	 * every KB of ring is a wave less per CU (160 KB of LDS) */
@@ -360,13 +359,13 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 		pl->oc = oc;
 		pl->ring = ring;
 		pl->nstrips = (g->W + oc - 1) / oc;
-		/* Rows per wave.  Every wave should be resident at once (one round): a CU holds
-		 * `per_cu` waves (LDS: ring + pads per wave, 160 KB per CU; registers: the cubic kernel
-		 * runs 2 waves per SIMD), and the waves of a launch spread evenly over the 256 CUs.  A
-		 * wave's time is (th + c) row times, c ~ 12 rows being its fixed cost (lane constants,
-		 * first window); a row time grows with the k = ceil(waves / 256) waves sharing a CU about
-		 * as 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9): mostly latency, partly
-		 * throughput. */
+		/* Rows per wave, chosen for a launch of ONE image (in a batch launch the waves of the
+		 * next image fill the slots as they free up and th = 29..113 measure the same).  Every
+		 * wave of the image should be resident at once (one round): a CU holds `per_cu` waves
+		 * (LDS: ring + pads per wave, 160 KB per CU), and the waves spread evenly over the 256
+		 * CUs.  A wave's time is (th + c) row times, c ~ 12 rows for its fixed cost and halo; a
+		 * row time grows with the k = ceil(waves / 256) waves sharing a CU about as
+		 * 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9). */
 		int per_cu = (160 * 1024) / (ring * ROLL_WIN * g->bpp + 512);
 		if (per_cu > 7) per_cu = 7;                     /* measured: 7 waves per CU beat 8 and 9 at equal total rows */
 		int best_th = 0;
