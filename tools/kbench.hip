@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void copy_u(const u32x4 *__restrict__ s, u32x4
 // ---- skeleton of the LDS-DMA row ring: global -> LDS (async, D rows ahead) -> registers -> global -------
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+#ifndef SKEL_LD_AUX
+#define SKEL_LD_AUX 0
+#endif
 template <int D, bool NTS>
 __global__ __launch_bounds__(256) void strip_copy(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int W, int H, int th, int nstrips, int nwaves, int K)
 {
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void strip_copy(const uint8_t *__restrict__ sr
 	auto issue = [&](int row) {
 		const uint8_t *g = src + (size_t)row * pitch + loff;
 		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-			(__attribute__((address_space(3))) void *)(myring + (row % K) * 1024), 16, 0, 0);
+			(__attribute__((address_space(3))) void *)(myring + (row % K) * 1024), 16, 0, SKEL_LD_AUX);
 	};
 #pragma unroll
 	for (int d = 0; d < D; ++d) if (Y0 + d < Y1) issue(Y0 + d);
