@@ -447,6 +447,43 @@ def test_full_size_configs(torch_cuda, case):
     assert np.array_equal(fast[..., 1], img[..., 1]) and np.array_equal(fast[..., 3], img[..., 3])
 
 
+@pytest.mark.parametrize("interp", [0, 2])
+def test_image_beyond_2gb_uses_64bit_addressing(torch_cuda, interp):
+    """24000 x 24000 RGBA8 = 2.3 GB per buffer: past the rolling kernel's 32-bit buffer offsets, so
+    the planner hands it to the kernels with 64-bit pointers; three row bands are checked against
+    the oracle (the bottom band's byte offsets exceed 2^31)."""
+    torch = torch_cuda
+    w = h = 24000
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=9000, lens_y=13000, interpolation=interp)
+    assert fixca.plan(w, h, 4, 1, p)[0] in (3, 4)
+    src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    fixca.fix_ca_region(src, dst, w, h, 4, 1, p, 0, w, 0, h, True)
+    torch.cuda.synchronize()
+    img = src.cpu().numpy()
+    po = pyoracle.make_params(**p.as_dict())
+    ref = np.zeros((64, w, 4), np.uint8)
+    for y1 in (0, 12000, h - 64):
+        full = pyoracle.region(img, po, y1=y1, y2=y1 + 64, dst=_scratch_like(img), threads=16)
+        ref[...] = full[y1:y1 + 64]
+        got = dst[y1:y1 + 64].cpu().numpy()
+        mx, _ = diff_stats(got, ref)
+        assert mx <= (0 if interp == 0 else TOL_LSB), (y1, mx)
+    del img, src, dst
+    torch.cuda.empty_cache()
+    _SCRATCH.clear()
+
+
+_SCRATCH = {}
+
+
+def _scratch_like(img):
+    """one reusable host buffer of the image's size (the oracle writes only the requested rows)"""
+    if "buf" not in _SCRATCH or _SCRATCH["buf"].shape != img.shape:
+        _SCRATCH["buf"] = np.empty_like(img)
+    return _SCRATCH["buf"]
+
+
 def test_directional_8192_config(torch_cuda):
     """config 4: 8192x8192 RGBA8, pure translation (both scales exactly 1), cubic."""
     case = [c for c in VEC["full"] if c["width"] == 8192][0]
