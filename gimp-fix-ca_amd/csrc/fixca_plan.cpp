@@ -313,7 +313,6 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 {
 	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < ROLL_WIN) return false;
-	if ((long long)g->W * g->H * g->bpp > (1LL << 31)) return false;       /* 32-bit buffer offsets, see k_roll */
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that
@@ -379,9 +378,12 @@ static bool plan_roll(const FixcaGeom *g, FixcaPlan *pl)
 			if (chunks == 1) break;
 		}
 		pl->th = env_int("FIXCA_TH", best_th, 1, 1 << 20);
+		/* k_roll addresses a wave's rows with 32-bit offsets into per-wave buffer descriptors */
+		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * g->W * g->bpp > (1LL << 31)) return false;
 		pl->nchunks = (rows + pl->th - 1) / pl->th;
 		if (pl->nchunks < 1) pl->nchunks = 1;
 		pl->nwaves = pl->nstrips * pl->nchunks;
+		if ((long long)pl->nwaves + 8 > (1LL << 31) / ROLL_BATCH_MAX) return false;     /* grid size of a batch launch */
 		pl->nblocks = (pl->nwaves + 7) & ~7;
 		return true;
 	}

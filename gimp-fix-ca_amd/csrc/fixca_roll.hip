@@ -560,12 +560,6 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	st.H = H;
 	st.pitch = (uint32_t)W * ROLL_BPP;
 	st.ring = lds + RING_PAD_LO;
-	{
-		/* descriptors are built from kernel arguments only, so they are provably wave-uniform */
-		const uint32_t total = (uint32_t)W * (uint32_t)H * ROLL_BPP;   /* <= 2 GB: the planner checks */
-		st.rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, total, 0x00020000);
-		st.rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total, 0x00020000);
-	}
 
 	/* ---- tables: strip header, first and last block descriptor (scalar loads) ------------ */
 	const cint_p strips = (cint_p)(const int *)tb.strips;
@@ -576,10 +570,19 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	st.lastneed = load_block(blocks, Y0 + nrows - 1).need1;
 	const int U0 = hd.U0;
 
+	/* Buffer descriptors of THIS wave's rows: source rows keep .. lastneed, output rows Y0 ..
+	 * Y0 + nrows - 1.  Offsets inside them are 32-bit (the planner keeps a wave's rows below 2 GB)
+	 * whatever the size of the image.  Built from kernel arguments and scalar loads only, so they
+	 * are provably wave-uniform. */
+	const uint32_t dst_bytes = (uint32_t)nrows * st.pitch;
+	st.rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + (size_t)b.keep * st.pitch, 0,
+	                                              (uint32_t)(st.lastneed - b.keep + 1) * st.pitch, 0x00020000);
+	st.rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)Y0 * st.pitch, 0, dst_bytes, 0x00020000);
+
 	/* start filling the ring before anything else */
 	st.ld = b.keep - 1;
 	st.vo_ld = (ROLL_BPP == 4) ? (uint32_t)(U0 + 4 * lane) * 4u : (uint32_t)U0 * 3u + 4u * (uint32_t)lane;
-	st.so_ld = (uint32_t)b.keep * st.pitch;
+	st.so_ld = 0;
 	{
 		const int target = min(min(b.need1 + RDEPTH, b.keep + st.KM), st.lastneed);
 		while (st.ld < target) roll_issue(st);
@@ -607,10 +610,10 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	st.tap[0] = (hd.tapR + 4 * min(lane, nact - NB)) * ROLL_BPP;
 	st.tap[1] = (hd.tapB + 4 * min(lane, nact - NB)) * ROLL_BPP;
 	st.my_idt = (uint32_t)((X0 - U0) + 4 * min(lane, nact - 1)) * ROLL_BPP;
-	/* a lane without output stores at offset `total`: past the end whether or not the range check
-	 * adds the scalar row offset (total <= 2 GB, so the sum cannot wrap) */
-	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : (uint32_t)W * (uint32_t)H * ROLL_BPP;
-	st.so_st = (uint32_t)Y0 * st.pitch;
+	/* a lane without output stores at the buffer's size: past the end whether or not the range
+	 * check adds the row offset (the size is below 2 GB, so the sum cannot wrap) */
+	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
+	st.so_st = 0;
 
 	auto run = [&](auto nw_tag) {
 		constexpr int NW = decltype(nw_tag)::value;

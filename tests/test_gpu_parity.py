@@ -448,14 +448,17 @@ def test_full_size_configs(torch_cuda, case):
 
 
 @pytest.mark.parametrize("interp", [0, 2])
-def test_image_beyond_2gb_uses_64bit_addressing(torch_cuda, interp):
-    """24000 x 24000 RGBA8 = 2.3 GB per buffer: past the rolling kernel's 32-bit buffer offsets, so
-    the planner hands it to the kernels with 64-bit pointers; three row bands are checked against
-    the oracle (the bottom band's byte offsets exceed 2^31)."""
+@pytest.mark.parametrize("force_fallback", [False, True], ids=["roll", "scan"])
+def test_image_beyond_2gb(torch_cuda, interp, force_fallback, monkeypatch):
+    """24000 x 24000 RGBA8 = 2.3 GB per buffer: byte offsets exceed 2^31.  The rolling kernel
+    addresses each wave's rows through its own buffer descriptor (32-bit offsets relative to it);
+    the fallback kernels use 64-bit pointers.  Three row bands are checked against the oracle."""
+    if force_fallback:
+        monkeypatch.setenv("FIXCA_NO_ROLL", "1")
     torch = torch_cuda
     w = h = 24000
     p = fixca.make_params(blue=2.0, red=-2.0, lens_x=9000, lens_y=13000, interpolation=interp)
-    assert fixca.plan(w, h, 4, 1, p)[0] in (3, 4)
+    assert fixca.plan(w, h, 4, 1, p)[0] == (4 if force_fallback else 6)
     src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda")
     dst = torch.empty_like(src)
     fixca.fix_ca_region(src, dst, w, h, 4, 1, p, 0, w, 0, h, True)
