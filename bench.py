@@ -106,7 +106,7 @@ def main():
 
     # rank 0 owns the parameters; everyone else receives them over RCCL
     params = fdist.broadcast_params(fixca.make_params(**PARAMS) if rank == 0 else None, src=0, device=dev)
-    kid, plan_text = fixca.plan(W, H, C, 1, params)
+    kid, plan_text = fixca.plan(W, H, C, 1, params, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)   # what fix_ca_batch will run
 
     B = max(4, args.batch)
     gen = torch.Generator(device=dev)

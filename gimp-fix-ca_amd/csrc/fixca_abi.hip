@@ -152,7 +152,7 @@ extern "C" int fixca_batch_device(const void *const *d_src, void *const *d_dst, 
 	FixcaPlan pl;
 	int rc = fixca_make_geom(W, H, bytes, bpc, params, 0, W, 0, H, 1, &g);
 	if (rc) return rc;
-	rc = fixca_make_plan(&g, flags, &pl);
+	rc = fixca_make_plan(&g, n_images > 1 ? (flags | FIXCA_PLAN_BATCH) : flags, &pl);
 	if (rc) return rc;
 	for (int i = 0; i < n_images; ++i)
 		if (!d_src[i] || !d_dst[i] || d_src[i] == d_dst[i])

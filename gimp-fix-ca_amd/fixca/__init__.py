@@ -21,6 +21,7 @@ _LIB_PATH = os.environ.get("FIXCA_LIB") or os.path.join(os.path.dirname(_PKG), "
 
 INTERP_NONE, INTERP_LINEAR, INTERP_CUBIC = 0, 1, 2
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_FAST = 0, 1, 2
+PLAN_BATCH = 4            # planning hint OR-ed into `kernel`: one of many equal calls (fix_ca_batch sets it)
 OK, E_INVALID, E_UNSUPPORTED, E_DOMAIN, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4, -5
 INPUT_MAX = 30
 

@@ -45,6 +45,8 @@ extern "C" {
                                     arithmetic: bit-exact in all three modes            */
 #define FIXCA_KERNEL_FAST   2u   /* fast kernel or FIXCA_E_UNSUPPORTED (tests, bench)   */
 #define FIXCA_KERNEL_MASK   3u
+#define FIXCA_PLAN_BATCH    4u   /* planning hint: the call is one of many of the same geometry launched back to
+                                    back (fixca_batch_device sets it): rows per wave are chosen for a full GPU */
 
 /*
  * Replaces the body of fix_ca_region (fix-ca.c:998-1348) for host buffers.

@@ -97,6 +97,8 @@ def test_planner_choices():
     cub = fixca.make_params(blue=2, red=-2, lens_x=658, lens_y=1280, interpolation=2)
     k, desc = fixca.plan(6000, 4000, 4, 1, cub)                         # RGBA, W % 4 == 0: LDS ring, rolling window
     assert k == 6 and "roll cubic" in desc and "oc=240" in desc and "ring=16" in desc   # 240 px = 960 B: 64-byte aligned stores
+    kb, descb = fixca.plan(6000, 4000, 4, 1, cub, kernel=fixca.PLAN_BATCH)  # one of many equal calls: shorter waves
+    assert kb == 6 and int(re.search(r"th=(\d+)", descb).group(1)) < int(re.search(r"th=(\d+)", desc).group(1))
     lin = fixca.make_params(blue=2, red=-2, lens_x=3000, lens_y=2000, interpolation=1)
     k, desc = fixca.plan(6000, 4000, 4, 1, lin)
     assert k == 6 and "roll linear" in desc
