@@ -366,10 +366,7 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		 * row time grows with the k = ceil(waves / 256) waves sharing a CU about as
 		 * 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9). */
 		int per_cu = (160 * 1024) / (ring * ROLL_WIN * g->bpp + 512);
-		/* one image alone: 7 waves per CU beat 8 and 9 at equal total rows (measured).  In a batch
-		 * launch the GPU stays full anyway and the LDS limit (9) with shorter waves measures 3 %
-		 * faster (th 45..49 against 57) */
-		if (!(flags & FIXCA_PLAN_BATCH) && per_cu > 7) per_cu = 7;
+		if (per_cu > 7) per_cu = 7;                     /* one image alone: 7 waves per CU beat 8 and 9 at equal total rows (measured) */
 		int best_th = 0;
 		long best_cost = 0;
 		for (int th = 16; th <= 1024; ++th) {
@@ -379,6 +376,14 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			const long cost = (27 + 5 * per) * (th + 12);
 			if (!best_th || cost < best_cost) { best_th = th; best_cost = cost; }
 			if (chunks == 1) break;
+		}
+		if (flags & FIXCA_PLAN_BATCH) {
+			/* many images back to back: the GPU stays full whatever the wave count, and short
+			 * waves (4 x the rows a wave keeps alive, so the halo stays ~20 %) measure best:
+			 * 6000x4000, span 7: th 33 -> 35.2 us per image, 44 -> 36.0, 57 -> 37.4 */
+			best_th = 4 * span + 5;
+			if (best_th < 24) best_th = 24;
+			if (best_th > 128) best_th = 128;
 		}
 		pl->th = env_int("FIXCA_TH", best_th, 1, 1 << 20);
 		/* k_roll addresses a wave's rows with 32-bit offsets into per-wave buffer descriptors */

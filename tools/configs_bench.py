@@ -18,7 +18,7 @@ for name, W, H, kw in CONFIGS:
     kw = dict(kw)
     C = kw.pop("channels", 4)
     p = fixca.make_params(**kw)
-    kid, desc = fixca.plan(W, H, C, 1, p)
+    kid, desc = fixca.plan(W, H, C, 1, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
     B = 12 if W == 6000 else 4
     srcs = [torch.randint(0, 256, (H, W, C), dtype=torch.uint8, device="cuda") for _ in range(B)]
     dsts = [torch.empty_like(s) for s in srcs]
