@@ -46,6 +46,7 @@
 #include "fixca_roll.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <type_traits>
 
 typedef float        f32x2 __attribute__((ext_vector_type(2)));
@@ -958,16 +959,15 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 	if (e != hipSuccess) return e;
 	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	if (const char *e = getenv("FIXCA_EXP_LDS_PAD")) lds += (size_t)atoi(e);      /* timing experiment: fewer waves per CU */
-	static bool attr_done = false;
-	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void *)k_roll<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		attr_done = true;
-	}
+	static std::once_flag attr_once;
+	std::call_once(attr_once, [] {
+		(void)hipFuncSetAttribute((const void *)k_roll<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		(void)hipFuncSetAttribute((const void *)k_roll<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+	});
 	const dim3 grid((unsigned)pl->nblocks * (unsigned)n_images);
 	const bool p2 = (pl->ring & (pl->ring - 1)) == 0;
 	if (p2) {

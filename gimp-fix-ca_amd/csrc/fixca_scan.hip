@@ -34,6 +34,7 @@
  * goes to the register-window kernel or the fp64 kernel in fixca_kernels.hip.
  */
 #include "fixca_device.h"
+#include <mutex>
 #include <type_traits>
 
 typedef float        f32x2 __attribute__((ext_vector_type(2)));
@@ -836,26 +837,24 @@ fixca_launch_scan(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 	uint8_t *d = static_cast<uint8_t *>(d_dst);
 	if (pl->kernel == FIXCA_K_SCANW) {
 		const size_t ldsw = (size_t)pl->ring * RING_ROW + 4 * WVX_BYTES;
-		static bool wattr = false;
-		if (!wattr) {
+		static std::once_flag wattr;
+		std::call_once(wattr, [] {
 			(void)hipFuncSetAttribute((const void *)k_scanw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			(void)hipFuncSetAttribute((const void *)k_scanw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			(void)hipFuncSetAttribute((const void *)k_scanw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			wattr = true;
-		}
+		});
 		if (g->interp == 0)      hipLaunchKernelGGL(k_scanw<0>, dim3(pl->nblocks), dim3(256), ldsw, stream, s, d, *g, *pl);
 		else if (g->interp == 1) hipLaunchKernelGGL(k_scanw<2>, dim3(pl->nblocks), dim3(256), ldsw, stream, s, d, *g, *pl);
 		else                     hipLaunchKernelGGL(k_scanw<4>, dim3(pl->nblocks), dim3(256), ldsw, stream, s, d, *g, *pl);
 		return hipGetLastError();
 	}
 	const size_t lds = (size_t)pl->ring * RING_ROW + 2 * VX_CH * 4;
-	static bool attr_done = false;
-	if (!attr_done) {
+	static std::once_flag attr_once;
+	std::call_once(attr_once, [] {
 		(void)hipFuncSetAttribute((const void *)k_scan<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_scan<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_scan<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		attr_done = true;
-	}
+	});
 	if (g->interp == 0)      hipLaunchKernelGGL(k_scan<0>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
 	else if (g->interp == 1) hipLaunchKernelGGL(k_scan<2>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
 	else                     hipLaunchKernelGGL(k_scan<4>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
