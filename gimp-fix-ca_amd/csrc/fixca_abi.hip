@@ -13,6 +13,7 @@
 #include "../../include/fixca_hip.h"
 #include "fixca_geom.h"
 #include "fixca_internal.h"
+#include "fixca_roll.h"
 
 extern "C" hipError_t fixca_launch(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_copy(const void *, void *, size_t, hipStream_t);
@@ -20,7 +21,7 @@ extern "C" hipError_t fixca_launch_centerline(void *, const FixcaGeom *, hipStre
 extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch_rgb(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
-/* a batch of images of one geometry: the row-rolling kernel takes up to 32 per launch, the
+/* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (64) per launch, the
  * other kernels one */
 static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
                        hipStream_t stream, int *launches);
@@ -165,8 +166,8 @@ static int launch_many(const void *const *d_src, void *const *d_dst, int n, cons
 {
 	int count = 0;
 	if (pl->kernel == FIXCA_K_ROLL && g->y2 > g->y1) {
-		for (int i = 0; i < n; i += 32) {
-			const int m = n - i < 32 ? n - i : 32;
+		for (int i = 0; i < n; i += ROLL_BATCH_MAX) {
+			const int m = n - i < ROLL_BATCH_MAX ? n - i : ROLL_BATCH_MAX;
 			if (g->bpp == 3) HIP_TRY(fixca_launch_roll_batch_rgb(d_src + i, d_dst + i, m, g, pl, stream));
 			else             HIP_TRY(fixca_launch_roll_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			++count;
@@ -181,9 +182,19 @@ static int launch_many(const void *const *d_src, void *const *d_dst, int n, cons
 	return FIXCA_OK;
 }
 
-/* fixca_region_host keeps its two device images between calls (grow only) */
-static void  *g_cache[2] = { NULL, NULL };
-static size_t g_cache_bytes = 0;
+/* fixca_region_host keeps its two device images between calls (grow only).  Per host thread and
+ * keyed by the device they were allocated on, like the pipeline streams and the table cache: two
+ * threads never share (or free) each other's images, and after fixca_set_device(n) the images of
+ * the previous device are dropped instead of being handed to kernels of another GPU.  A thread
+ * that exits without fixca_release_cache() leaves its images allocated until the process ends. */
+namespace {
+struct HostCache {
+	void  *buf[2] = { nullptr, nullptr };
+	size_t bytes = 0;
+	int    device = -1;
+};
+thread_local HostCache g_cache;
+}
 
 extern "C" void fixca_roll_release_tables(void);
 extern "C" void fixca_roll_release_tables_rgb(void);
@@ -193,10 +204,19 @@ extern "C" void fixca_release_cache(void)
 	fixca_roll_release_tables();
 	fixca_roll_release_tables_rgb();
 	for (int i = 0; i < 2; ++i) {
-		if (g_cache[i]) (void)hipFree(g_cache[i]);
-		g_cache[i] = NULL;
+		if (g_cache.buf[i]) (void)hipFree(g_cache.buf[i]);
+		g_cache.buf[i] = nullptr;
 	}
-	g_cache_bytes = 0;
+	g_cache.bytes = 0;
+	g_cache.device = -1;
+}
+
+/* test hook: the calling thread's cached device images (NULL before the first host call) */
+extern "C" __attribute__((visibility("default"))) void fixca_debug_host_cache(void **src_image, void **dst_image, size_t *nbytes)
+{
+	if (src_image) *src_image = g_cache.buf[0];
+	if (dst_image) *dst_image = g_cache.buf[1];
+	if (nbytes) *nbytes = g_cache.bytes;
 }
 
 /* rows above / below an output row that its taps can reach: |y' - y| <= |s - 1| * (distance of the
@@ -248,29 +268,30 @@ static int pipe_init(void)
 	return FIXCA_OK;
 }
 
-extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, int W, int H, int bytes,
-                                 int bpc, const FixCaParams *params, int x1, int x2, int y1, int y2,
-                                 int show_progress)
+/* the body of fixca_region_host; on a failure it may return with copies and kernels still queued */
+static int region_host_queue(const unsigned char *src, unsigned char *dst, int W, int H, int bytes,
+                             int bpc, const FixCaParams *params, int x1, int x2, int y1, int y2,
+                             int show_progress, const FixcaGeom &g)
 {
-	if (!src || !dst) return fixca_fail(FIXCA_E_INVALID, "null image pointer");
-	FixcaGeom g;
-	int rc = fixca_make_geom(W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, &g);
-	if (rc) return rc;                       /* argument errors are reported without touching the GPU */
-	rc = require_device();
-	if (rc) return rc;
-	if (y2 <= y1) return FIXCA_OK;
-
+	int rc;
 	const size_t pitch = (size_t)W * bytes, total = pitch * H;
-	if (total > g_cache_bytes) {
-		fixca_release_cache();
-		HIP_TRY(hipMalloc(&g_cache[0], total));
-		HIP_TRY(hipMalloc(&g_cache[1], total));
-		g_cache_bytes = total;
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (total > g_cache.bytes || dev != g_cache.device) {
+		for (int i = 0; i < 2; ++i) {
+			if (g_cache.buf[i]) (void)hipFree(g_cache.buf[i]);
+			g_cache.buf[i] = nullptr;
+		}
+		g_cache.bytes = 0;
+		g_cache.device = dev;
+		HIP_TRY(hipMalloc(&g_cache.buf[0], total));
+		HIP_TRY(hipMalloc(&g_cache.buf[1], total));
+		g_cache.bytes = total;
 	}
 	const char *ex = getenv("FIXCA_EXACT");
 	const unsigned flags = (ex && *ex && strcmp(ex, "0") != 0) ? FIXCA_KERNEL_EXACT : FIXCA_KERNEL_AUTO;
-	char *const d_src = static_cast<char *>(g_cache[0]);
-	char *const d_dst = static_cast<char *>(g_cache[1]);
+	char *const d_src = static_cast<char *>(g_cache.buf[0]);
+	char *const d_dst = static_cast<char *>(g_cache.buf[1]);
 
 	/* only the source rows the requested rows can reach are uploaded (the preview asks for a
 	 * window of rows, fix-ca.c:656) */
@@ -279,8 +300,7 @@ extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, i
 	const int hi = y2 + reach < H ? y2 + reach : H;
 	const int rows = y2 - y1;
 
-	const char *np = getenv("FIXCA_NO_PIPELINE");
-	if (rows < 256 || (np && *np && strcmp(np, "0") != 0) || !is_pinned(src) || !is_pinned(dst)) {
+	if (rows < 256 || fixca_debug_flag("FIXCA_NO_PIPELINE") || !is_pinned(src) || !is_pinned(dst)) {
 		HIP_TRY(hipMemcpy(d_src + (size_t)lo * pitch, src + (size_t)lo * pitch, (size_t)(hi - lo) * pitch, hipMemcpyHostToDevice));
 		rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, flags, NULL);
 		if (rc) return rc;
@@ -308,10 +328,7 @@ extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, i
 		HIP_TRY(hipEventRecord(g_pipe.uploaded[band], g_pipe.up));
 		HIP_TRY(hipStreamWaitEvent(g_pipe.run, g_pipe.uploaded[band], 0));
 		rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, x1, x2, yb, ye, show_progress, flags, g_pipe.run);
-		if (rc) {
-			(void)hipDeviceSynchronize();
-			return rc;
-		}
+		if (rc) return rc;
 		HIP_TRY(hipEventRecord(g_pipe.done[band], g_pipe.run));
 		HIP_TRY(hipStreamWaitEvent(g_pipe.down, g_pipe.done[band], 0));
 		HIP_TRY(hipMemcpyAsync(dst + (size_t)yb * pitch, d_dst + (size_t)yb * pitch, (size_t)(ye - yb) * pitch,
@@ -321,6 +338,30 @@ extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, i
 	HIP_TRY(hipStreamSynchronize(g_pipe.run));
 	HIP_TRY(hipStreamSynchronize(g_pipe.up));
 	return FIXCA_OK;
+}
+
+extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, int W, int H, int bytes,
+                                 int bpc, const FixCaParams *params, int x1, int x2, int y1, int y2,
+                                 int show_progress)
+{
+	if (!src || !dst) return fixca_fail(FIXCA_E_INVALID, "null image pointer");
+	FixcaGeom g;
+	int rc = fixca_make_geom(W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, &g);
+	if (rc) return rc;                       /* argument errors are reported without touching the GPU */
+	rc = require_device();
+	if (rc) return rc;
+	if (y2 <= y1) return FIXCA_OK;
+	rc = region_host_queue(src, dst, W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, g);
+	if (rc != FIXCA_OK) {
+		/* One exit for every failure: nothing of this call may still be running when the caller
+		 * gets its buffers back (on a non-zero return the plug-in's own loop
+		 * writes the same dst).  Queued downloads would land in dst and queued uploads would read
+		 * src behind the caller's back, so the device is drained first; the error text of the
+		 * first failure is kept. */
+		(void)hipDeviceSynchronize();
+		(void)hipGetLastError();
+	}
+	return rc;
 }
 
 /* ---- timing on the launch stream ---------------------------------------- */

@@ -12,6 +12,11 @@ int fixca_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 
 int  fixca_make_geom(int W, int H, int bytes, int bpc, const FixCaParams *p,
                      int x1, int x2, int y1, int y2, int show_progress, FixcaGeom *g);
 int  fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl);
+/* Tuning and experiment knobs (FIXCA_TH, FIXCA_OC, FIXCA_RING, FIXCA_ABLATE, FIXCA_NO_ROLL, ...) are
+ * honoured only when FIXCA_DEBUG is set to a non-zero value: a stray variable in the environment
+ * of a GIMP session must not change the kernels' shape.  Returns dflt otherwise. */
+int  fixca_debug_env(const char *name, int dflt, int lo, int hi);
+bool fixca_debug_flag(const char *name);
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n);
 
 #endif

@@ -122,8 +122,15 @@ int fixca_make_geom(int W, int H, int bytes, int bpc, const FixCaParams *p,
 	return FIXCA_OK;
 }
 
-static int env_int(const char *name, int dflt, int lo, int hi)
+static bool debug_on(void)
 {
+	const char *d = getenv("FIXCA_DEBUG");
+	return d && *d && strcmp(d, "0") != 0;
+}
+
+int fixca_debug_env(const char *name, int dflt, int lo, int hi)
+{
+	if (!debug_on()) return dflt;
 	const char *e = getenv(name);
 	if (!e || !*e) return dflt;
 	int v = atoi(e);
@@ -131,6 +138,15 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 	if (v > hi) v = hi;
 	return v;
 }
+
+bool fixca_debug_flag(const char *name)
+{
+	if (!debug_on()) return false;
+	const char *e = getenv(name);
+	return e && *e && strcmp(e, "0") != 0;
+}
+
+static int env_int(const char *name, int dflt, int lo, int hi) { return fixca_debug_env(name, dflt, lo, hi); }
 
 /* does every strip's source window fit the 256 columns a wave filters? */
 static bool interp_fits(const FixcaGeom *g, int oc, int taps)
@@ -208,7 +224,7 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 	if ((long long)g->W * g->H * 4 >= (1LL << 40)) return false;
 	const int taps = (g->interp == 0) ? 0 : (g->interp == 1 ? 2 : 4);
 	const int span = scan_row_span(g, taps);
-	const bool shared = getenv("FIXCA_SCANW") != NULL;  /* 4-wave shared-ring variant only on request (it is not faster yet) */
+	const bool shared = fixca_debug_flag("FIXCA_SCANW");  /* 4-wave shared-ring variant only on request (it is not faster yet) */
 	int ring = env_int("FIXCA_RING", 0, 0, 64);
 	if (shared) {
 		/* a group of 4 rows keeps span + 3 rows alive, the previous group 4 more, plus 8 in flight */
@@ -224,7 +240,7 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 		if (!scan_cols_fit(g, oc, taps)) continue;
 		pl->kernel = shared ? FIXCA_K_SCANW : FIXCA_K_SCAN;
 		pl->oc = oc;
-		pl->th = env_int("FIXCA_TH", 64, 1, 1 << 20);
+		pl->th = env_int("FIXCA_TH", 64, 1, 4096);
 		pl->ring = ring;
 		pl->ablate = env_int("FIXCA_ABLATE", 0, 0, 3);
 		int rows = g->y2 - g->y1;
@@ -385,7 +401,7 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			if (best_th < 24) best_th = 24;
 			if (best_th > 128) best_th = 128;
 		}
-		pl->th = env_int("FIXCA_TH", best_th, 1, 1 << 20);
+		pl->th = env_int("FIXCA_TH", best_th, 1, 4096);
 		/* k_roll addresses a wave's rows with 32-bit offsets into per-wave buffer descriptors */
 		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * g->W * g->bpp > (1LL << 31)) return false;
 		pl->nchunks = (rows + pl->th - 1) / pl->th;
@@ -396,6 +412,67 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		return true;
 	}
 	return false;
+}
+
+/* The two-level tile schedule of one k_roll launch (RollSched, fixca_roll.h).
+ *
+ * Measured on MI355X (tools/kbench2.hip, the kernel's data movement without its arithmetic, 16 images
+ * of 6000x4000): dynamically dispatched tiles of 33 rows 69.6 - 70.8 % of the HBM peak, big pieces
+ * on 87 % of the slots covering 50 - 80 % of the rows plus pool tiles 72.9 - 75.0 %, flat over that
+ * range.  A launch of big pieces only is slower than either whenever the pieces do not divide
+ * evenly over the CUs or one wave runs slow (the launch ends with its slowest wave), which is what
+ * the pool prevents. */
+void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, int resident, RollSched *sc)
+{
+	memset(sc, 0, sizeof *sc);
+	const int rows = g->y2 - g->y1;
+	sc->ncols = n_images * pl->nstrips;
+	sc->rows = rows;
+	sc->th = pl->th;
+	long long nbig = 0, L = 0, Hb = 0;
+	/* Big pieces are OFF unless asked for (FIXCA_DEBUG_RESIDENT under FIXCA_DEBUG): in the skeleton
+	 * they gain 4 - 5 points, in k_roll itself they lose 5 - 7 (35.0 -> 37.4 us per image, with and
+	 * without the filter arithmetic), not yet understood; the decode and tests stay so that the
+	 * comparison can be repeated. */
+	if (resident > 0 && n_images > 1 && rows >= 8 * pl->th) {
+		/* 90 % of the slots: a piece that found no slot would start when the first piece ends and
+		 * double the launch time, so the count stays clear of the occupancy estimate */
+		nbig = (long long)resident * 9 / 10;
+		Hb = ((long long)rows * 3 / 4) & ~3LL;          /* three quarters of the rows */
+		const long long total = (long long)sc->ncols * Hb;
+		L = ((total + nbig - 1) / nbig + 3) & ~3LL;
+		/* pieces worth having: several pool tiles long, and short enough for k_roll's 32-bit
+		 * offsets inside a wave's rows (the halo is at most 2 * FIXCA_SOURCE_ROWS more) */
+		if (L < 4 * pl->th || (L + 2 * FIXCA_SOURCE_ROWS) * (long long)g->W * g->bpp > (1LL << 31)) {
+			nbig = 0; L = 0; Hb = 0;
+		} else {
+			nbig = (total + L - 1) / L;
+		}
+	}
+	sc->nbig = (int)nbig;
+	sc->big_blocks = (int)((nbig + 7) & ~7LL);
+	sc->L = (int)L;
+	sc->Hb = (int)Hb;
+	sc->pool_chunks = (int)((rows - Hb + pl->th - 1) / pl->th);
+	sc->pool_waves = pl->nstrips * sc->pool_chunks;
+	sc->pool_blocks = (sc->pool_waves + 7) & ~7;
+}
+
+/* test hook (CPU): the schedule as numbers */
+extern "C" __attribute__((visibility("default"))) int fixca_debug_sched(int W, int H, int bytes, const FixCaParams *p, int n_images, int resident, int *out10)
+{
+	FixcaGeom g;
+	FixcaPlan pl;
+	int rc = fixca_make_geom(W, H, bytes, 1, p, 0, W, 0, H, 1, &g);
+	if (rc) return rc;
+	rc = fixca_make_plan(&g, n_images > 1 ? FIXCA_PLAN_BATCH : 0u, &pl);
+	if (rc) return rc;
+	if (pl.kernel != FIXCA_K_ROLL) return fixca_fail(FIXCA_E_UNSUPPORTED, "not a k_roll geometry");
+	RollSched sc;
+	roll_make_sched(&g, &pl, n_images, resident, &sc);
+	const int v[10] = { sc.ncols, sc.rows, sc.nbig, sc.big_blocks, sc.L, sc.Hb, sc.pool_chunks, sc.pool_waves, sc.pool_blocks, sc.th };
+	memcpy(out10, v, sizeof v);
+	return FIXCA_OK;
 }
 
 static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
@@ -414,7 +491,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH", "FIXCA_ABLATE" };
 
 static void env_signature(char *buf, size_t n)
@@ -461,9 +538,9 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		return FIXCA_OK;
 	}
 
-	if (!getenv("FIXCA_NO_ROLL") && plan_roll(g, flags, pl)) return FIXCA_OK;
+	if (!fixca_debug_flag("FIXCA_NO_ROLL") && plan_roll(g, flags, pl)) return FIXCA_OK;
 	memset(pl, 0, sizeof *pl);
-	if (!getenv("FIXCA_NO_SCAN") && plan_scan(g, pl)) return FIXCA_OK;
+	if (!fixca_debug_flag("FIXCA_NO_SCAN") && plan_scan(g, pl)) return FIXCA_OK;
 	memset(pl, 0, sizeof *pl);
 	pl->kernel = FIXCA_K_EXACT;
 

@@ -49,10 +49,47 @@ struct RollTables {
 };
 
 /* the images of one launch (independent, same geometry and parameters): a kernel argument */
-#define ROLL_BATCH_MAX 32
+#define ROLL_BATCH_MAX 64
 struct RollBatch {
 	const uint8_t *src[ROLL_BATCH_MAX];
 	uint8_t       *dst[ROLL_BATCH_MAX];
 };
+
+/* The tile schedule of one launch (a kernel argument, built by roll_make_sched in fixca_plan.cpp).
+ *
+ * A column is one strip of one image; the launch has ncols = n_images * nstrips of them, each
+ * `rows` output rows tall.  Two kinds of tile, both handled by one wave:
+ *
+ *  - BIG pieces.  The first Hb rows of all columns, laid end to end (column 0's rows, then column
+ *    1's, ...), are cut into nbig pieces of L rows; piece k is workgroup k.  There are fewer big
+ *    pieces than wave slots on the chip, so all of them are resident from the start and each
+ *    streams through its rows with no halo re-read and no pipeline restart (a piece that crosses
+ *    a column boundary restarts once there).  Their work is about three quarters of the launch,
+ *    so they finish well before the end.
+ *  - POOL tiles: the remaining rows [Hb, rows) of every column in chunks of `th` rows, in the
+ *    workgroups after the big ones.  The dispatcher hands them to whichever slots are free: the
+ *    few slots the big pieces left over at first, every slot once the big pieces are done.  They
+ *    absorb the speed differences between waves, CUs and XCDs and keep the tail of the launch
+ *    short.
+ *
+ * nbig == 0 (one image, or a geometry too small for pieces worth having): pool tiles only,
+ * Hb == 0, which is the schedule of round 1. */
+struct RollSched {
+	int ncols;          /* n_images * nstrips                                                     */
+	int rows;           /* y2 - y1                                                                */
+	int nbig;           /* big pieces (0: none)                                                   */
+	int big_blocks;     /* workgroups reserved for them: nbig rounded up to a multiple of 8        */
+	int L;              /* rows per big piece, a multiple of 4                                    */
+	int Hb;             /* rows of every column that belong to big pieces, a multiple of 4         */
+	int pool_chunks;    /* pool chunks per column: ceil((rows - Hb) / th)                          */
+	int pool_waves;     /* pool tiles per image: nstrips * pool_chunks                             */
+	int pool_blocks;    /* workgroups per image for them: pool_waves rounded up to a multiple of 8 */
+	int th;             /* rows per pool tile                                                     */
+};
+
+/* fixca_plan.cpp: resident = wave slots of the chip for this kernel (waves per CU x CUs), 0 = unknown */
+struct FixcaGeom;
+struct FixcaPlan;
+void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, int resident, RollSched *sc);
 
 #endif

@@ -44,6 +44,7 @@
  */
 #include "fixca_device.h"
 #include "fixca_roll.h"
+#include "fixca_internal.h"
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -517,36 +518,18 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	STAMP(4);                                       /* conversions + stores */
 }
 
-template <int TAPS, bool P2>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
-__global__ __launch_bounds__(64) void
-k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
+/* one tile: output rows [Y0, Y0 + nrows) of strip `strip` of image `img` */
+template <int TAPS, bool P2>
+__device__ __forceinline__ void
+roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPlan &pl, const RollTables &tb,
+          int img, int strip, int Y0, int nrows)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	constexpr int T = TAPS;
-
-	/* One launch covers a batch of independent images: workgroups [k*nblocks, (k+1)*nblocks)
-	 * are image k's tiles (nblocks is a multiple of 8, so the XCD remap is per image).  The
-	 * dispatcher hands out workgroups in order, so image k+1's first waves start in the slots
-	 * image k's last waves leave: no fill/drain bubble per image. */
-	const int img = blockIdx.x / pl.nblocks;
 	const int lane = threadIdx.x;
-	const int bid = blockIdx.x - img * pl.nblocks;
-	int tile = xcd_remap(bid, pl.nblocks);
-#if defined(FIXCA_EXP_ORDER)                    /* timing experiment: tile order */
-	if (pl.ablate == 1) tile = bid;                                  /* consecutive tiles on different XCDs */
-#endif
-	if (tile >= pl.nwaves) return;
 	const uint8_t *__restrict__ src = imgs.src[img];
 	uint8_t *__restrict__ dst = imgs.dst[img];
-	int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
-#if defined(FIXCA_EXP_ORDER)
-	if (pl.ablate == 2) { chunk = tile % pl.nchunks; strip = tile / pl.nchunks; }          /* strip-major within the XCD range */
-	if (pl.ablate == 3) { tile = bid; chunk = tile % pl.nchunks; strip = tile / pl.nchunks; }
-#endif
 	const int W = g.W, H = g.H, oc = pl.oc;
 	const int X0 = strip * oc;                      /* the last strip may be narrower: its extra lanes store nothing */
-	const int Y0 = g.y1 + chunk * pl.th;
-	const int nrows = min(pl.th, g.y2 - Y0);
 
 	RollState<TAPS, P2> st;
 	st.lane = threadIdx.x;
@@ -571,8 +554,8 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 	st.lastneed = load_block(blocks, Y0 + nrows - 1).need1;
 	const int U0 = hd.U0;
 
-	/* Buffer descriptors of THIS wave's rows: source rows keep .. lastneed, output rows Y0 ..
-	 * Y0 + nrows - 1.  Offsets inside them are 32-bit (the planner keeps a wave's rows below 2 GB)
+	/* Buffer descriptors of THIS tile's rows: source rows keep .. lastneed, output rows Y0 ..
+	 * Y0 + nrows - 1.  Offsets inside them are 32-bit (the planner keeps a tile's rows below 2 GB)
 	 * whatever the size of the image.  Built from kernel arguments and scalar loads only, so they
 	 * are provably wave-uniform. */
 	const uint32_t dst_bytes = (uint32_t)nrows * st.pitch;
@@ -650,9 +633,53 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb)
 		if (lane == 7) v = hd.gen;
 		if (lane == 5) v = __builtin_amdgcn_s_memrealtime() - rt_begin;   /* 100 MHz ticks; replaces the prologue slot */
 		if (lane == 4) v = rt_begin;
-		reinterpret_cast<unsigned long long *>(dst)[(size_t)tile * 8 + lane] = v;
+		reinterpret_cast<unsigned long long *>(dst)[(size_t)blockIdx.x * 8 + lane] = v;
 	}
 #endif
+}
+
+template <int TAPS, bool P2>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
+__global__ __launch_bounds__(64) void
+k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+	/* One launch covers a batch of independent images; the schedule is described at RollSched
+	 * (fixca_roll.h).  Everything below is wave-uniform scalar arithmetic on kernel arguments. */
+	const int bx = blockIdx.x;
+	if (bx < sc.big_blocks) {
+		/* a big piece: rows [f0, f1) of the columns' first Hb rows laid end to end */
+		if (bx >= sc.nbig) return;
+		long long f0 = (long long)bx * sc.L;
+		const long long f1 = min(f0 + sc.L, (long long)sc.ncols * sc.Hb);
+		while (f0 < f1) {
+			const int col = (int)(f0 / sc.Hb);
+			const int yy = (int)(f0 - (long long)col * sc.Hb);
+			const int n = (int)min((long long)(sc.Hb - yy), f1 - f0);
+			const int img = col / pl.nstrips;
+			roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, col - img * pl.nstrips, g.y1 + yy, n);
+			f0 += n;
+		}
+		return;
+	}
+	/* a pool tile.  Workgroups [k * pool_blocks, (k + 1) * pool_blocks) after the big ones are image
+	 * k's tiles (pool_blocks is a multiple of 8, so the XCD remap is per image): image k+1's first
+	 * waves start in the slots image k's last waves leave, no fill/drain bubble per image. */
+	const int pb = bx - sc.big_blocks;
+	const int img = pb / sc.pool_blocks;
+	const int bid = pb - img * sc.pool_blocks;
+	int tile = xcd_remap(bid, sc.pool_blocks);
+#if defined(FIXCA_EXP_ORDER)                    /* timing experiment: tile order */
+	if (pl.ablate == 1) tile = bid;                                  /* consecutive tiles on different XCDs */
+#endif
+	if (tile >= sc.pool_waves) return;
+	int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
+#if defined(FIXCA_EXP_ORDER)
+	if (pl.ablate == 2) { chunk = tile % sc.pool_chunks; strip = tile / sc.pool_chunks; }          /* strip-major within the XCD range */
+	if (pl.ablate == 3) { tile = bid; chunk = tile % sc.pool_chunks; strip = tile / sc.pool_chunks; }
+#endif
+	const int Y0 = g.y1 + sc.Hb + chunk * sc.th;
+	roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0));
 }
 
 /* ======================================================================================
@@ -851,7 +878,7 @@ struct TableEntry {
 	hipEvent_t  ready = nullptr;
 	unsigned long long used = 0;
 };
-constexpr int TABLE_ENTRIES = 4;
+constexpr int TABLE_ENTRIES = 8;
 thread_local TableEntry g_tc[TABLE_ENTRIES];
 thread_local unsigned long long g_tick = 0;
 }
@@ -875,10 +902,10 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	if (e != hipSuccess) return e;
 	for (TableEntry &t : g_tc) {
 		if (t.valid && t.device == dev && t.oc == pl->oc && memcmp(&t.g, &key, sizeof key) == 0) {
-			if (stream != t.built_on) {              /* another stream: order it after the table kernel */
-				e = hipStreamWaitEvent(stream, t.ready, 0);
-				if (e != hipSuccess) return e;
-			}
+			/* always ordered after the table kernel: a stream handle can be destroyed and handed out
+			 * again, so "the stream that built them" proves nothing, and the wait costs next to nothing */
+			e = hipStreamWaitEvent(stream, t.ready, 0);
+			if (e != hipSuccess) return e;
 			t.used = ++g_tick;
 			*out = t.tb;
 			return hipSuccess;
@@ -894,7 +921,8 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	}
 	TableEntry &t = *slot;
 	if (t.valid) {
-		/* eviction: kernels on any stream may still be reading this entry's tables */
+		/* eviction: kernels on any stream may still be reading this entry's tables.  (Not legal
+		 * inside a stream capture: a capture must not bring a 9th geometry; fixca_hip.h says so.) */
 		e = hipDeviceSynchronize();
 		if (e != hipSuccess) return e;
 		t.valid = false;
@@ -943,6 +971,22 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	return hipSuccess;
 }
 
+/* wave slots of the current device for one k_roll instantiation with `lds` bytes of dynamic LDS
+ * (waves per CU x CUs); 0 when the runtime cannot tell */
+template <typename K>
+static int resident_slots(K kernel, size_t lds)
+{
+	int dev = 0, cus = 0, per_cu = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess) return 0;
+	/* the LDS allocation is the binding limit for this kernel (160 KB per CU); never trust a higher answer */
+	const int by_lds = (int)((160u * 1024u) / (lds ? lds : 1));
+	if (per_cu > by_lds) per_cu = by_lds;
+	if (per_cu < 1 || cus < 1) return 0;
+	return per_cu * cus;
+}
+
 /* n_images images (1 .. ROLL_BATCH_MAX) in one launch */
 extern "C" hipError_t
 ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g,
@@ -958,7 +1002,7 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 	hipError_t e = ensure_tables(g, pl, stream, &tb);
 	if (e != hipSuccess) return e;
 	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
-	if (const char *e = getenv("FIXCA_EXP_LDS_PAD")) lds += (size_t)atoi(e);      /* timing experiment: fewer waves per CU */
+	lds += (size_t)fixca_debug_env("FIXCA_EXP_LDS_PAD", 0, 0, 128 * 1024);      /* timing experiment: fewer waves per CU */
 	static std::once_flag attr_once;
 	std::call_once(attr_once, [] {
 		(void)hipFuncSetAttribute((const void *)k_roll<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -968,18 +1012,34 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 		(void)hipFuncSetAttribute((const void *)k_roll<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_roll<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 	});
-	const dim3 grid((unsigned)pl->nblocks * (unsigned)n_images);
 	const bool p2 = (pl->ring & (pl->ring - 1)) == 0;
+	auto launch = [&](auto kernel) -> hipError_t {
+		/* the schedule depends on how many waves of THIS kernel the chip holds at once: asked once
+		 * per instantiation, LDS size and device */
+		static thread_local struct { bool valid; int dev; size_t lds; int slots; } memo;
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		if (!memo.valid || memo.dev != dev || memo.lds != lds) {
+			memo.slots = resident_slots(kernel, lds);
+			memo.valid = true; memo.dev = dev; memo.lds = lds;
+		}
+		/* big pieces only on request: see roll_make_sched */
+		const int want = fixca_debug_env("FIXCA_DEBUG_RESIDENT", 0, -1, 1 << 20);
+		const int slots = want < 0 ? memo.slots : want;
+		RollSched sc;
+		roll_make_sched(g, pl, n_images, slots, &sc);
+		const dim3 grid((unsigned)sc.big_blocks + (unsigned)sc.pool_blocks * (unsigned)n_images);
+		hipLaunchKernelGGL(kernel, grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+		return hipGetLastError();
+	};
 	if (p2) {
-		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-		else                     hipLaunchKernelGGL((k_roll<4, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-	} else {
-		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
-		else                     hipLaunchKernelGGL((k_roll<4, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb);
+		if (g->interp == 0)      return launch(k_roll<1, true>);
+		else if (g->interp == 1) return launch(k_roll<2, true>);
+		else                     return launch(k_roll<4, true>);
 	}
-	return hipGetLastError();
+	if (g->interp == 0)      return launch(k_roll<1, false>);
+	else if (g->interp == 1) return launch(k_roll<2, false>);
+	return launch(k_roll<4, false>);
 }
 
 extern "C" hipError_t

@@ -96,6 +96,8 @@ def _load():
                                  ctypes.POINTER(ctypes.c_double)], ci),
         "fixca_time_copy": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ctypes.c_size_t, vp,
                              ctypes.POINTER(ctypes.c_double)], ci),
+        "fixca_debug_sched": ([ci, ci, ci, P, ci, ci, ctypes.POINTER(ci)], ci),
+        "fixca_debug_host_cache": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)], None),
         "fixca_last_error": ([], ctypes.c_char_p),
         "fixca_abi_version": ([], ci),
     }
@@ -194,6 +196,24 @@ def fix_ca_batch(srcs, dsts, orig_width, orig_height, bytes, bpc, params, kernel
     _check(lib.fixca_batch_device(_ptr_array(srcs), _ptr_array(dsts), len(srcs), orig_width, orig_height,
                                   bytes, bpc, ctypes.byref(params), kernel, _current_stream()))
     return dsts
+
+
+SCHED_FIELDS = ("ncols", "rows", "nbig", "big_blocks", "L", "Hb", "pool_chunks", "pool_waves", "pool_blocks", "th")
+
+
+def debug_sched(orig_width, orig_height, bytes, params, n_images, resident):
+    """k_roll's tile schedule for a batch launch of n_images on a chip with `resident` wave slots
+    (0: unknown -> pool tiles only), as a dict; works without a GPU.  Test hook."""
+    out = (ctypes.c_int * 10)()
+    _check(lib.fixca_debug_sched(orig_width, orig_height, bytes, ctypes.byref(params), n_images, resident, out))
+    return dict(zip(SCHED_FIELDS, list(out)))
+
+
+def debug_host_cache():
+    """(src image, dst image, bytes) of the calling thread's fixca_region_host device cache.  Test hook."""
+    a, b, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+    lib.fixca_debug_host_cache(ctypes.byref(a), ctypes.byref(b), ctypes.byref(n))
+    return a.value, b.value, n.value
 
 
 def time_launches(srcs, dsts, launches, orig_width, orig_height, bytes, bpc, params, kernel=KERNEL_AUTO):

@@ -138,6 +138,15 @@ FIXCA_API int fixca_time_copy(const void *const *d_src, void *const *d_dst, int 
 FIXCA_API const char *fixca_last_error(void);          /* thread-local, never NULL     */
 FIXCA_API int         fixca_abi_version(void);         /* 1                            */
 
+/* ---- test hooks (used by tests/ only) ----------------------------------------------------
+ * fixca_debug_sched: the tile schedule of a batch launch of the row-rolling kernel as 10 ints
+ * {ncols, rows, nbig, big_blocks, L, Hb, pool_chunks, pool_waves, pool_blocks, th} for a chip with
+ * `resident` wave slots (no GPU needed).  fixca_debug_host_cache: the calling thread's cached
+ * device images of fixca_region_host. */
+FIXCA_API int  fixca_debug_sched(int orig_width, int orig_height, int bytes, const FixCaParams *params,
+                                 int n_images, int resident, int *out10);
+FIXCA_API void fixca_debug_host_cache(void **src_image, void **dst_image, size_t *nbytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,3 +56,90 @@ def test_model_smooth_image_mostly_exact():
     out = kernel_model.run(img, p, 252)
     mx, n = diff_stats(out, ref)
     assert mx <= 1 and n <= 0.001 * ref.size
+
+
+# ---- k_roll's two-level tile schedule (RollSched, csrc/fixca_roll.h) ---------------------------------
+
+def _decode_sched(sc, nstrips):
+    """what k_roll's workgroups do with a schedule: list of (column, first row, rows), big pieces first"""
+    tiles = []
+    for k in range(sc["nbig"]):
+        f0, f1 = k * sc["L"], min((k + 1) * sc["L"], sc["ncols"] * sc["Hb"])
+        while f0 < f1:
+            col, yy = divmod(f0, sc["Hb"])
+            n = min(sc["Hb"] - yy, f1 - f0)
+            tiles.append((col, yy, n, "big", k))
+            f0 += n
+    nimg = sc["ncols"] // nstrips
+    for img in range(nimg):
+        th = sc["th"]
+        for t in range(sc["pool_waves"]):
+            strip, chunk = t % nstrips, t // nstrips
+            y0 = sc["Hb"] + chunk * th
+            tiles.append((img * nstrips + strip, y0, min(th, sc["rows"] - y0), "pool", t))
+    return tiles
+
+
+@pytest.mark.parametrize("shape", [(6000, 4000, 4, 16, 2304), (6000, 4000, 4, 64, 2304), (6000, 4000, 3, 33, 2304),
+                                   (8192, 8192, 4, 4, 2304), (768, 400, 4, 8, 20), (6000, 4000, 4, 2, 2304),
+                                   (6000, 4000, 4, 16, 0), (1024, 257, 4, 5, 2304)])
+def test_roll_schedule_covers_every_row_once(shape):
+    w, h, c, n, resident = shape
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=w * 0.11, lens_y=h * 0.32, interpolation=2)
+    kid, desc = fixca.plan(w, h, c, 1, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
+    assert kid == 6, desc
+    nstrips = int(re.search(r"strips=(\d+)", desc).group(1))
+    sc = fixca.debug_sched(w, h, c, p, n, resident)
+    assert sc["ncols"] == n * nstrips and sc["rows"] == h
+    assert sc["L"] % 4 == 0 and sc["Hb"] % 4 == 0 and sc["big_blocks"] % 8 == 0 and sc["pool_blocks"] % 8 == 0
+    assert sc["big_blocks"] >= sc["nbig"] and sc["pool_blocks"] >= sc["pool_waves"]
+    if resident == 0:
+        assert sc["nbig"] == 0 and sc["Hb"] == 0
+    else:
+        assert sc["nbig"] <= resident * 9 // 10 + 1          # all big pieces resident at once, with room to spare
+    if shape[:4] == (6000, 4000, 4, 16):
+        if resident:
+            assert sc["nbig"] > 1500 and 2500 <= sc["Hb"] <= 3200 and sc["L"] >= 400, sc
+    cover = np.zeros((sc["ncols"], h), np.int32)
+    piece_rows = {}
+    for col, y0, nr, kind, k in _decode_sched(sc, nstrips):
+        assert nr > 0 and 0 <= y0 and y0 + nr <= h
+        cover[col, y0:y0 + nr] += 1
+        if kind == "big":
+            piece_rows[k] = piece_rows.get(k, 0) + nr
+    assert np.all(cover == 1)
+    if piece_rows:
+        assert max(piece_rows.values()) == sc["L"] and min(piece_rows.values()) > 0
+
+
+def test_tuning_knobs_need_debug(monkeypatch):
+    """FIXCA_TH and friends change the plan only under FIXCA_DEBUG (a stray variable in a GIMP
+    session's environment must not reshape the kernels)"""
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=2)
+    monkeypatch.delenv("FIXCA_DEBUG", raising=False)
+    base = fixca.plan(6000, 4000, 4, 1, p)[1]
+    monkeypatch.setenv("FIXCA_TH", "7")
+    monkeypatch.setenv("FIXCA_NO_ROLL", "1")
+    assert fixca.plan(6000, 4000, 4, 1, p)[1] == base
+    monkeypatch.setenv("FIXCA_DEBUG", "1")
+    k, desc = fixca.plan(6000, 4000, 4, 1, p)
+    assert k != 6 and desc != base
+    monkeypatch.delenv("FIXCA_NO_ROLL")
+    assert "th=7 " in fixca.plan(6000, 4000, 4, 1, p)[1]
+    monkeypatch.setenv("FIXCA_DEBUG", "0")
+    assert fixca.plan(6000, 4000, 4, 1, p)[1] == base
+
+
+def test_host_cache_is_per_thread():
+    """fixca_region_host's cached device images belong to the calling thread: nothing is
+    shared through a process-wide static, so one thread can never free what another is using"""
+    import threading
+    seen = {}
+
+    def worker(name):
+        seen[name] = fixca.debug_host_cache()
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert seen[0] == (None, None, 0) and seen[1] == (None, None, 0)
