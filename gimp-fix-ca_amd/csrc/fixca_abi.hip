@@ -17,11 +17,13 @@
 
 extern "C" hipError_t fixca_launch(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_copy(const void *, void *, size_t, hipStream_t);
+extern "C" hipError_t fixca_launch_noise(void *, size_t, unsigned long long, hipStream_t);
+extern "C" hipError_t fixca_launch_preview(const void *, void *, int, int, int, int, int, int, int, hipStream_t);
 extern "C" hipError_t fixca_launch_centerline(void *, const FixcaGeom *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch_rgb(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
-/* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (64) per launch, the
+/* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (32) per launch, the
  * other kernels one */
 static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
                        hipStream_t stream, int *launches);
@@ -362,6 +364,91 @@ extern "C" int fixca_region_host(const unsigned char *src, unsigned char *dst, i
 		(void)hipGetLastError();
 	}
 	return rc;
+}
+
+/* ---- the preview caller (fix-ca.c:617-679) --------------------------------- */
+
+static int preview_args_check(int W, int H, int bytes, int bpc, int x, int y, int width, int height)
+{
+	const int sb = bpc < 0 ? -bpc : bpc;
+	if (!(bpc == 1 || bpc == 2 || bpc == 4 || bpc == -4 || bpc == -8) || (bytes != 3 * sb && bytes != 4 * sb))
+		return fixca_fail(FIXCA_E_UNSUPPORTED, "bpc=%d bytes=%d: implemented are RGB/RGBA with u8, u16, u32, float or double samples", bpc, bytes);
+	if (W <= 0 || H <= 0 || x < 0 || y < 0 || width < 0 || height < 0 || x > W - width || y > H - height)
+		return fixca_fail(FIXCA_E_INVALID, "preview window %dx%d at (%d,%d) outside the %dx%d image", width, height, x, y, W, H);
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_preview_device(const void *d_img, void *d_prev, int W, int H, int bytes, int bpc,
+                                    int x, int y, int width, int height, void *stream)
+{
+	if (!d_img || !d_prev) return fixca_fail(FIXCA_E_INVALID, "null image pointer");
+	int rc = preview_args_check(W, H, bytes, bpc, x, y, width, height);
+	if (rc) return rc;
+	HIP_TRY(fixca_launch_preview(d_img, d_prev, W, bytes, bpc, x, y, width, height, (hipStream_t)stream));
+	return FIXCA_OK;
+}
+
+static int preview_host_queue(const unsigned char *src, unsigned char *prev, int W, int H, int bytes, int bpc,
+                              const FixCaParams *params, int x, int y, int width, int height, const FixcaGeom &g)
+{
+	const size_t pitch = (size_t)W * bytes, total = pitch * H;
+	const int sb = bpc < 0 ? -bpc : bpc;
+	const size_t prev_bytes = (size_t)width * height * (bytes / sb);
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (total > g_cache.bytes || dev != g_cache.device) {
+		for (int i = 0; i < 2; ++i) {
+			if (g_cache.buf[i]) (void)hipFree(g_cache.buf[i]);
+			g_cache.buf[i] = nullptr;
+		}
+		g_cache.bytes = 0;
+		g_cache.device = dev;
+		HIP_TRY(hipMalloc(&g_cache.buf[0], total));
+		HIP_TRY(hipMalloc(&g_cache.buf[1], total));
+		g_cache.bytes = total;
+	}
+	char *const d_src = static_cast<char *>(g_cache.buf[0]);
+	char *const d_dst = static_cast<char *>(g_cache.buf[1]);
+	const int reach = vertical_reach(&g);
+	const int lo = y - reach > 0 ? y - reach : 0;
+	const int hi = y + height + reach < H ? y + height + reach : H;
+	HIP_TRY(hipMemcpy(d_src + (size_t)lo * pitch, src + (size_t)lo * pitch, (size_t)(hi - lo) * pitch, hipMemcpyHostToDevice));
+	int rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, 0, W, y, y + height, 0, FIXCA_KERNEL_AUTO, NULL);
+	if (rc) return rc;
+	/* the window is converted into the (already consumed) upload area: no third buffer */
+	void *d_prev = d_src;
+	HIP_TRY(fixca_launch_preview(d_dst, d_prev, W, bytes, bpc, x, y, width, height, NULL));
+	HIP_TRY(hipMemcpy(prev, d_prev, prev_bytes, hipMemcpyDeviceToHost));
+	return FIXCA_OK;
+}
+
+extern "C" int fixca_preview_host(const unsigned char *src, unsigned char *prev, int W, int H, int bytes, int bpc,
+                                  const FixCaParams *params, int x, int y, int width, int height)
+{
+	if (!src || !prev) return fixca_fail(FIXCA_E_INVALID, "null image pointer");
+	int rc = preview_args_check(W, H, bytes, bpc, x, y, width, height);
+	if (rc) return rc;
+	FixcaGeom g;
+	rc = fixca_make_geom(W, H, bytes, bpc, params, 0, W, y, y + height, 0, &g);
+	if (rc) return rc;
+	rc = require_device();
+	if (rc) return rc;
+	if (width == 0 || height == 0) return FIXCA_OK;
+	rc = preview_host_queue(src, prev, W, H, bytes, bpc, params, x, y, width, height, g);
+	if (rc != FIXCA_OK) {
+		(void)hipDeviceSynchronize();
+		(void)hipGetLastError();
+	}
+	return rc;
+}
+
+/* ---- synthetic input ----------------------------------------- */
+
+extern "C" int fixca_noise_device(void *d_dst, size_t nbytes, unsigned long long seed, void *stream)
+{
+	if (!d_dst) return fixca_fail(FIXCA_E_INVALID, "null pointer");
+	HIP_TRY(fixca_launch_noise(d_dst, nbytes, seed, (hipStream_t)stream));
+	return FIXCA_OK;
 }
 
 /* ---- timing on the launch stream ---------------------------------------- */

@@ -45,6 +45,7 @@ struct FixcaPlan {
 #define FIXCA_K_SCAN    4
 #define FIXCA_K_SCANW   5   /* scan with the ring shared by the 4 waves of a workgroup */
 #define FIXCA_K_ROLL    6   /* LDS ring, horizontal-first rolling window (fixca_roll.hip) */
+#define FIXCA_K_WCOL    7   /* u16 / u32 / float / double samples: fp64 rolling window (fixca_wide.hip) */
 
 #define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
 

@@ -621,6 +621,53 @@ fixca_launch_centerline(void *d_dst, const FixcaGeom *g, hipStream_t stream)
 }
 
 /* ------------------------------------------------------------------------ */
+/* k_preview: the tail of preview_update() (fix-ca.c:659-671): the visible      */
+/* window of the corrected image, samples wider than 8 bits converted with      */
+/* get_pixel -> set_pixel(.., 1).  One thread per output sample.                */
+/* ------------------------------------------------------------------------ */
+
+/* (guchar) round(d * 255) as gcc/x86-64 evaluates it (fix-ca.c:752): in range of a 32-bit integer -> its
+ * low byte, otherwise (or NaN) 0x80000000 -> 0.  In-range values 0..255 are what every image in
+ * [0,1] produces; the rest only pins down what the reference does with out-of-range floats. */
+__device__ __forceinline__ uint8_t u8_as_x86(double r)
+{
+	const int i = (r >= -2147483648.0 && r < 2147483648.0) ? (int)r : (-2147483647 - 1);
+	return (uint8_t)((uint32_t)i & 0xffu);
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void
+k_preview(const S *__restrict__ img, uint8_t *__restrict__ prev, int W, int nch, int x, int y, int width, int height)
+{
+	const int n = width * nch;                      /* samples per window row */
+	const int i = blockIdx.y;
+	const S *row = img + ((size_t)W * (y + i) + x) * nch;
+	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256)
+		prev[(size_t)i * n + j] = u8_as_x86(round(__dmul_rn(SampleCodec<S>::get(row[j]), 255.0)));
+}
+
+extern "C" hipError_t
+fixca_launch_preview(const void *d_img, void *d_prev, int W, int bytes, int bpc, int x, int y, int width, int height, hipStream_t stream)
+{
+	if (width <= 0 || height <= 0) return hipSuccess;
+	const int b = bpc < 0 ? -bpc : bpc, nch = bytes / b;
+	if (b == 1)                                      /* a plain crop (fix-ca.c:661-664) */
+		return hipMemcpy2DAsync(d_prev, (size_t)width * bytes, static_cast<const uint8_t *>(d_img) + ((size_t)W * y + x) * bytes,
+		                        (size_t)W * bytes, (size_t)width * bytes, height, hipMemcpyDeviceToDevice, stream);
+	const int n = width * nch;
+	const dim3 grid((n + 255) / 256 < 64 ? (n + 255) / 256 : 64, height), block(256);
+	uint8_t *prev = static_cast<uint8_t *>(d_prev);
+	switch (bpc) {
+	case 2:  hipLaunchKernelGGL(k_preview<uint16_t>, grid, block, 0, stream, static_cast<const uint16_t *>(d_img), prev, W, nch, x, y, width, height); break;
+	case 4:  hipLaunchKernelGGL(k_preview<uint32_t>, grid, block, 0, stream, static_cast<const uint32_t *>(d_img), prev, W, nch, x, y, width, height); break;
+	case -4: hipLaunchKernelGGL(k_preview<float>, grid, block, 0, stream, static_cast<const float *>(d_img), prev, W, nch, x, y, width, height); break;
+	case -8: hipLaunchKernelGGL(k_preview<double>, grid, block, 0, stream, static_cast<const double *>(d_img), prev, W, nch, x, y, width, height); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
 /* bandwidth yardstick: 16 bytes per lane straight copy                      */
 /* ------------------------------------------------------------------------ */
 
@@ -636,6 +683,34 @@ k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 	for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&s[i]), &d[i]);
 }
 
+/* SURVEY §8d's synthetic input on the device: byte i of noise(seed) is byte (i mod 8) of SplitMix64
+ * word i/8 + 1 = mix(seed + (i/8 + 1) * GOLDEN), little-endian: the same bytes as
+ * fixca/synth.py noise_bytes (tests/test_gpu_parity.py compares them). */
+__global__ __launch_bounds__(256) void
+k_noise(uint8_t *__restrict__ dst, size_t nbytes, unsigned long long seed)
+{
+	const size_t nwords = (nbytes + 7) / 8;
+	for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (size_t)gridDim.x * 256) {
+		unsigned long long z = seed + (unsigned long long)(w + 1) * 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z ^= z >> 31;
+		if (8 * w + 8 <= nbytes) {
+			*reinterpret_cast<unsigned long long *>(dst + 8 * w) = z;         /* buffers from hipMalloc are 256-byte aligned */
+		} else {
+			for (size_t b = 8 * w; b < nbytes; ++b) dst[b] = (uint8_t)(z >> (8 * (b - 8 * w)));
+		}
+	}
+}
+
+extern "C" hipError_t fixca_launch_noise(void *d_dst, size_t nbytes, unsigned long long seed, hipStream_t stream)
+{
+	if (!nbytes) return hipSuccess;
+	if (reinterpret_cast<uintptr_t>(d_dst) & 7) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_noise, dim3(8192), dim3(256), 0, stream, static_cast<uint8_t *>(d_dst), nbytes, seed);
+	return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------ */
 /* launchers (called from fixca_abi.hip)                                     */
 /* ------------------------------------------------------------------------ */
@@ -643,6 +718,7 @@ k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 extern "C" hipError_t fixca_launch_scan(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_rgb(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_wide(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
 extern "C" hipError_t
 fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
@@ -678,6 +754,8 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 	case FIXCA_K_SCAN:
 	case FIXCA_K_SCANW:
 		return fixca_launch_scan(d_src, d_dst, g, pl, stream);
+	case FIXCA_K_WCOL:
+		return fixca_launch_wide(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_ROLL:
 		return g->bpp == 3 ? fixca_launch_roll_rgb(d_src, d_dst, g, pl, stream) : fixca_launch_roll(d_src, d_dst, g, pl, stream);
 	default:

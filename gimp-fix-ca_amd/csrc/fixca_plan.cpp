@@ -16,6 +16,7 @@
 #include "fixca_geom.h"
 #include "fixca_internal.h"
 #include "fixca_roll.h"
+#include "fixca_wide.h"
 
 static double h_coord(int i, int centre, double s, double shift)
 {
@@ -485,13 +486,42 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
 	pl->nblocks = ((pl->nwaves + 3) / 4 + 7) & ~7;
 }
 
+/* ---- plan for the wide-sample rolling kernel (fixca_wide.hip) ------------------------- */
+
+/* k_wcol gives every channel its own 128-column window starting at the (even-rounded) first tap of
+ * the strip's first column; every tap of every column of the strip must fall inside it */
+static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
+{
+	if (g->interp == 0 || g->bpc == 1 || g->W < 2) return false;
+	if ((long long)g->W * g->H >= (1LL << 40)) return false;
+	const int taps = (g->interp == 2) ? 4 : 2, back = (taps == 4) ? 1 : 0, W = g->W;
+	const int oc = WIDE_OC;
+	for (int c = 0; c < 2; ++c)
+		for (int X0 = 0; X0 < W; X0 += oc) {
+			const int xl = (X0 + oc < W ? X0 + oc : W) - 1;
+			const int f = clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1) & ~1;
+			const int l = clampi((int)floor(h_map_dbl(xl, g->xc, W, g->s[c], g->xs[c])) - back + taps - 1, 0, W - 1);
+			if (l - f > WIDE_WIN - 1) return false;
+			/* the map is monotone for s > 0, so no column of the strip reaches below f or above l */
+		}
+	pl->kernel = FIXCA_K_WCOL;
+	pl->oc = oc;
+	pl->th = env_int("FIXCA_TH", 64, 1, WIDE_TH_MAX);
+	pl->nstrips = (W + oc - 1) / oc;
+	pl->nchunks = (g->y2 - g->y1 + pl->th - 1) / pl->th;
+	if (pl->nchunks < 1) pl->nchunks = 1;
+	pl->nwaves = pl->nstrips * pl->nchunks;
+	pl->nblocks = (pl->nwaves + 7) & ~7;
+	return true;
+}
+
 static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl);
 
 /* The planner walks every column and row of the image (tens of microseconds for 6000x4000,
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_WCOL", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH", "FIXCA_ABLATE" };
 
 static void env_signature(char *buf, size_t n)
@@ -531,10 +561,14 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	pl->kernel = FIXCA_K_EXACT;
 	if (want == FIXCA_KERNEL_EXACT) return FIXCA_OK;
 	if (g->bpc != 1) {
-		/* 16/32-bit and floating-point samples: the fp64 kernel (bit-exact, one thread per pixel)
-		 * is the only implementation so far */
+		/* 16/32-bit and floating-point samples: the rolling fp64 kernel for LINEAR / CUBIC (bit-exact
+		 * like the one-thread-per-pixel kernel, which stays for NONE, a plain gather, and as the
+		 * fallback for scales that drift more than a window over one strip) */
+		if (!fixca_debug_flag("FIXCA_NO_WCOL") && plan_wide(g, pl)) return FIXCA_OK;
+		memset(pl, 0, sizeof *pl);
+		pl->kernel = FIXCA_K_EXACT;
 		if (want == FIXCA_KERNEL_FAST)
-			return fixca_fail(FIXCA_E_UNSUPPORTED, "no fast kernel for bpc=%d yet", g->bpc);
+			return fixca_fail(FIXCA_E_UNSUPPORTED, "no fast kernel for bpc=%d interpolation %d at this scale", g->bpc, g->interp);
 		return FIXCA_OK;
 	}
 
@@ -575,11 +609,14 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n)
 {
-	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "scanw", "roll" };
+	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "scanw", "roll", "wide-roll-fp64" };
 	static const char *in[] = { "none", "linear", "cubic" };
 	if (!buf || !n) return;
 	if (pl->kernel == FIXCA_K_EXACT)
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, g->bpc, (g->W + 255) / 256, g->y2 - g->y1);
+	else if (pl->kernel == FIXCA_K_WCOL)
+		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d strips=%d chunks=%d waves=%d", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
+		         pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves);
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

@@ -195,18 +195,14 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
 		__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 16, st.vo_ld, st.so_ld, 1024, ROLL_LD_AUX);
 #endif
 #else
-	/* A 12-byte LDS-DMA puts lane L's bytes at 16 L (a 4-byte hole after every 4 pixels), so the
-	 * 768-byte row segment is moved as three 256-byte pieces of one dword per lane instead: the
-	 * ring row stays contiguous.  (The instruction offset applies to the global AND the LDS
-	 * address, so all pieces use the same LDS base.) */
+	/* RGB8: the 768 bytes of a ring row (256 pixels x 3) are moved by ONE LDS-DMA of 16 bytes per
+	 * lane with 48 lanes active: contiguous in memory and in LDS (lane L's bytes land at 16 L).
+	 * Round 1 used three one-dword-per-lane pieces (a 12-byte DMA would leave a 4-byte hole after
+	 * every 4 pixels): three times the VMEM instructions of RGBA, the main reason RGB8 ran at 56 %
+	 * of the HBM peak against RGBA's 67 %.  The global address is only 4-byte aligned (U0 * 3). */
 	__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(st.ring + slot * RING_ROW);
-	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
-	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 256, ROLL_LD_AUX);
-	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 512, ROLL_LD_AUX);
-#if ROLL_WIN > 256
-	if (st.lane < (ROLL_WIN - 256) * 3 / 4)          /* columns 256 .. 271: 48 bytes */
-		__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 4, st.vo_ld, st.so_ld, 768, ROLL_LD_AUX);
-#endif
+	if (st.lane < RING_ROW / 16)
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
 #endif
 #endif
 	st.so_ld += st.pitch;
@@ -217,7 +213,7 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
  * vmcnt counts loads and stores together.  Loads complete in order among loads and stores among
  * stores, but the compiler's own model of gfx9-family hardware does not order a load against a
  * store (a young store may be acknowledged before an old load has landed), so the wait relies
- * on loads only: rows are loaded in order, one load each (three for RGB), so exactly ld - need
+ * on loads only: rows are loaded in order, one load each, so exactly ld - need
  * rows' loads are younger than the one needed, and "at most ld - need operations outstanding" implies "at most
  * ld - need loads outstanding", which implies the needed row is in LDS.  Stores in flight make
  * the wait stricter, never wrong. */
@@ -229,7 +225,7 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
 #if defined(FIXCA_EXP_NOVMWAIT)                 /* timing experiment only: reads rows that may not have landed */
 	return;
 #endif
-	constexpr int LPR = ((ROLL_BPP == 4) ? 1 : 3) + ((ROLL_WIN > 256) ? 1 : 0);     /* loads per row */
+	constexpr int LPR = 1 + ((ROLL_WIN > 256) ? 1 : 0);     /* loads per row */
 	const int younger = st.ld - need;
 	if (younger >= 8) roll_wait_vm<8 * LPR>();
 	else if (younger >= 6) roll_wait_vm<6 * LPR>();
@@ -565,7 +561,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 
 	/* start filling the ring before anything else */
 	st.ld = b.keep - 1;
-	st.vo_ld = (ROLL_BPP == 4) ? (uint32_t)(U0 + 4 * lane) * 4u : (uint32_t)U0 * 3u + 4u * (uint32_t)lane;
+	st.vo_ld = (ROLL_BPP == 4) ? (uint32_t)(U0 + 4 * lane) * 4u : (uint32_t)U0 * 3u + 16u * (uint32_t)lane;
 	st.so_ld = 0;
 	{
 		const int target = min(min(b.need1 + RDEPTH, b.keep + st.KM), st.lastneed);

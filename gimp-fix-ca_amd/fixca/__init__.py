@@ -96,6 +96,9 @@ def _load():
                                  ctypes.POINTER(ctypes.c_double)], ci),
         "fixca_time_copy": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ctypes.c_size_t, vp,
                              ctypes.POINTER(ctypes.c_double)], ci),
+        "fixca_preview_host": ([vp, vp, ci, ci, ci, ci, P, ci, ci, ci, ci], ci),
+        "fixca_preview_device": ([vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp], ci),
+        "fixca_noise_device": ([vp, ctypes.c_size_t, ctypes.c_ulonglong, vp], ci),
         "fixca_debug_sched": ([ci, ci, ci, P, ci, ci, ctypes.POINTER(ci)], ci),
         "fixca_debug_host_cache": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)], None),
         "fixca_last_error": ([], ctypes.c_char_p),
@@ -196,6 +199,25 @@ def fix_ca_batch(srcs, dsts, orig_width, orig_height, bytes, bpc, params, kernel
     _check(lib.fixca_batch_device(_ptr_array(srcs), _ptr_array(dsts), len(srcs), orig_width, orig_height,
                                   bytes, bpc, ctypes.byref(params), kernel, _current_stream()))
     return dsts
+
+
+def preview(img, params, bpc, x, y, width, height):
+    """preview_update()'s pixels (fix-ca.c:617-679) for a host image `img` (numpy, H x W x C samples):
+    rows [y, y+height) corrected as the preview does (show_progress FALSE), the window cropped and
+    samples wider than 8 bits converted to 8 bits.  Returns height x width x C uint8."""
+    h, w, c = img.shape
+    bytes_pp = img.strides[1]
+    out = np.zeros((height, width, c), np.uint8) if abs(bpc) != 1 else np.zeros((height, width, bytes_pp), np.uint8)
+    _check(lib.fixca_preview_host(img.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), w, h,
+                                  bytes_pp, bpc, ctypes.byref(params), x, y, width, height))
+    return out
+
+
+def noise_fill(t, seed):
+    """Fill the device tensor `t` (uint8, contiguous) with SURVEY §8d's noise(seed) on torch's current stream."""
+    assert t.is_contiguous() and t.element_size() == 1
+    _check(lib.fixca_noise_device(ctypes.c_void_p(t.data_ptr()), t.numel(), seed & 0xFFFFFFFFFFFFFFFF, _current_stream()))
+    return t
 
 
 SCHED_FIELDS = ("ncols", "rows", "nbig", "big_blocks", "L", "Hb", "pool_chunks", "pool_waves", "pool_blocks", "th")

@@ -76,6 +76,20 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 	return 0;
 }
 
+int fixca_preview_pixels(const FixcaDrawable *d, FixCaParams *params,
+                         int x, int y, int width, int height, unsigned char *prevImg)
+{
+	if (!d || !d->pixels || !params || !prevImg) return -1;
+	if (d->bpc <= -99) return -1;                           /* fix-ca.c:642-643: the preview stays as it is */
+	fixca_host_status = fixca_preview_host(d->pixels, prevImg, d->width, d->height, d->bpp, d->bpc,
+	                                       params, x, y, width, height);
+	if (fixca_host_status != FIXCA_OK) {
+		fprintf(stderr, "fix-ca (HIP): %s (code %d)\n", fixca_last_error(), fixca_host_status);
+		return -1;
+	}
+	return 0;
+}
+
 int fixca_unmarshal_noninteractive(int nparams, const FixcaPdbArg *param, FixCaParams *out)
 {
 	if (!param || !out || nparams < 5 || nparams > 12)     /* fix-ca.c:231-235 */

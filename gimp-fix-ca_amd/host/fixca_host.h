@@ -8,6 +8,9 @@
  *                      (FixcaDrawable) because libgimp/GEGL are not in this image
  *     run()            the PDB entry; its non-interactive argument handling is
  *                      fixca_unmarshal_noninteractive() below
+ *     preview_update() the second caller of fix_ca_region (fix-ca.c:617-679): its pixel
+ *                      work between the GEGL fetch and gimp_preview_draw_buffer is
+ *                      fixca_preview_pixels() below
  * glib's typedefs are spelled out (gint = int, guchar = unsigned char,
  * gboolean = int, gdouble = double) so the file builds with or without glib.
  */
@@ -42,6 +45,16 @@ typedef struct FixcaDrawable {
 /* fix_ca() (fix-ca.c:332-394): 0 on success, -1 on empty selection, unsupported
  * colour type or GPU failure.  Processes the rows of the selection rectangle. */
 int fix_ca(FixcaDrawable *drawable, FixCaParams *params);
+
+/*
+ * preview_update()'s pixels (fix-ca.c:647-671): the drawable's rows [y, y+height) corrected with
+ * show_progress FALSE, the visible window (x, y, width, height) copied to prevImg, samples wider
+ * than 8 bits converted to 8 bits (get_pixel -> set_pixel(.., 1)).  prevImg must hold
+ * width * height * bpp / |bpc| bytes (what gimp_preview_draw_buffer is then given with rowstride
+ * width * bpp / |bpc|, fix-ca.c:673).  The drawable is not modified.  0 on success, -1 otherwise.
+ */
+int fixca_preview_pixels(const FixcaDrawable *drawable, FixCaParams *params,
+                         int x, int y, int width, int height, unsigned char *prevImg);
 
 /* color_size() (fix-ca.c:681-711) from a babl format name and bytes per pixel. */
 int fixca_color_size(const char *babl_format_name, int bytes_per_pixel);

@@ -117,6 +117,34 @@ FIXCA_API void *fixca_host_alloc(size_t nbytes);       /* NULL on failure       
 FIXCA_API int   fixca_host_free(void *h_ptr);
 FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_host's buffers and the kernel tables */
 
+/* ---- the preview caller --------------------------------------------------- */
+/*
+ * preview_update() (fix-ca.c:617-679) between gegl_buffer_get and gimp_preview_draw_buffer:
+ * corrects rows [y, y + height) of the whole image with show_progress = FALSE (the lens-centre
+ * lines are drawn, fix-ca.c:1326; saturation != 0 is refused), copies the visible window
+ * (x, y, width, height) into prev and, when the samples are wider than 8 bits, converts them with
+ * get_pixel -> set_pixel(.., 1) (fix-ca.c:665-669).  prev receives width * height * bytes bytes for
+ * bpc = 1 and width * height * (bytes / |bpc|) bytes otherwise: what gimp_preview_draw_buffer is
+ * given (rowstride width * bytes / |bpc|, fix-ca.c:673).
+ *
+ * fixca_preview_device is the crop + conversion alone, on an image already on the device (d_prev
+ * must not overlap the window it is cut from).
+ */
+FIXCA_API int fixca_preview_host(const unsigned char *src, unsigned char *prev,
+                                 int orig_width, int orig_height, int bytes, int bpc,
+                                 const FixCaParams *params, int x, int y, int width, int height);
+FIXCA_API int fixca_preview_device(const void *d_img, void *d_prev,
+                                   int orig_width, int orig_height, int bytes, int bpc,
+                                   int x, int y, int width, int height, void *stream);
+
+/* ---- synthetic input ------------------------------------------------------ */
+/*
+ * Fills d_dst (8-byte aligned device memory) with the first nbytes of SURVEY.md §8(d)'s noise(seed):
+ * the SplitMix64 stream, word k >= 1 = mix(seed + k * 0x9E3779B97F4A7C15), little-endian.  Used by
+ * bench.py to make config 5's 512 images (image i = noise(0xF1CA1000 + i)) without a host copy.
+ */
+FIXCA_API int fixca_noise_device(void *d_dst, size_t nbytes, unsigned long long seed, void *stream);
+
 /* ---- timing on the launch stream (bench.py's roofline leg) -------------- */
 /*
  * Runs `launches` back-to-back kernel launches over the n_pairs src/dst pairs in

@@ -15,6 +15,7 @@
  *   bilinear()                 :882-894
  *   cubicY() / cubicX()        :896-920    Catmull-Rom, columns then rows
  *   centerline()               :945-996    preview cross-hair (show_progress=0)
+ *   preview_update()           :659-671    crop of the visible window + 8-bit down-conversion
  *   load_data()/set_data()     :822-871    a 120-row cache that is
  *                                          semantically row(y) = src[y]; not
  *                                          reproduced, only its meaning.
@@ -340,6 +341,45 @@ fixca_oracle_region_mt(const unsigned char *src, unsigned char *dst,
 		}
 	}
 	return rc;
+}
+
+/*
+ * The tail of preview_update() (fix-ca.c:659-671): the visible window (x, y, width, height) of
+ * the corrected image `img` (orig_width pixels wide, what fix_ca_region wrote with
+ * show_progress = 0) is copied into `prev`; samples wider than 8 bits go through
+ * get_pixel -> set_pixel(.., 1), i.e. prev = (guchar) round(get_pixel(sample) * 255).
+ * prev holds width * height * (bytes / |bpc|) bytes when |bpc| != 1, width * height * bytes otherwise.
+ *
+ * set_pixel stores the double into a guchar (fix-ca.c:752): for values outside 0..255 (float
+ * images may hold any value in green/alpha, and in red/blue with interpolation None) C leaves the
+ * conversion undefined; gcc on x86-64, the reference's platform, truncates to a 32-bit integer
+ * (cvttsd2si: 0x80000000 when out of range or NaN) and keeps the low byte.  That is spelled out
+ * here so that the oracle does not depend on its own compiler.
+ */
+static unsigned char u8_as_x86(double r)
+{
+	int32_t i = (r >= -2147483648.0 && r < 2147483648.0) ? (int32_t)r : INT32_MIN;
+	return (unsigned char)((uint32_t)i & 0xffu);
+}
+
+ORACLE_API int
+fixca_oracle_preview(const unsigned char *img, unsigned char *prev, int orig_width, int orig_height,
+                     int bytes, int bpc, int x, int y, int width, int height)
+{
+	const int b = iabs(bpc);
+	if (x < 0 || y < 0 || width < 0 || height < 0 || x + width > orig_width || y + height > orig_height) return -1;
+	if (!(bpc == 1 || bpc == 2 || bpc == 4 || bpc == -4 || bpc == -8) || bytes < 3 * b) return -2;
+	for (int i = 0; i < height; ++i) {
+		const unsigned char *row = img + ((size_t)orig_width * (y + i) + x) * bytes;
+		if (b == 1) {
+			memcpy(prev + (size_t)width * i * bytes, row, (size_t)width * bytes);
+		} else {
+			const int n = width * bytes / b;
+			for (int j = 0; j < n; ++j)
+				prev[(size_t)width * i * bytes / b + j] = u8_as_x86(round(sample_get(row + (size_t)j * b, bpc) * 255));
+		}
+	}
+	return 0;
 }
 
 ORACLE_API int fixca_oracle_has_openmp(void)

@@ -57,6 +57,8 @@ def _load(omp=False):
         lib.fixca_oracle_region.restype = ctypes.c_int
         lib.fixca_oracle_region_mt.argtypes = args + [ctypes.c_int]
         lib.fixca_oracle_region_mt.restype = ctypes.c_int
+        lib.fixca_oracle_preview.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8
+        lib.fixca_oracle_preview.restype = ctypes.c_int
         _libs[key] = lib
     return _libs[key]
 
@@ -82,3 +84,18 @@ def region(src: np.ndarray, params: FixCaParams, bpc=1, y1=0, y2=None,
     if rc != 0:
         raise ValueError("oracle refused the call: rc=%d" % rc)
     return dst
+
+
+def preview(img: np.ndarray, bpc, x, y, width, height):
+    """The tail of preview_update() (fix-ca.c:659-671): crop the window and convert samples wider than
+    8 bits to 8 bits.  `img` is the corrected image (H x W x C samples).  Returns height x width x C uint8
+    (bpc == 1: the cropped bytes)."""
+    assert img.flags["C_CONTIGUOUS"] and img.ndim == 3
+    h, w = img.shape[0], img.shape[1]
+    bytes_pp = img.strides[1]
+    nch = bytes_pp // abs(bpc)
+    out = np.zeros((height, width, nch), np.uint8)
+    rc = _load().fixca_oracle_preview(img.ctypes.data, out.ctypes.data, w, h, bytes_pp, bpc, x, y, width, height)
+    if rc != 0:
+        raise ValueError("oracle refused the preview call: rc=%d" % rc)
+    return out

@@ -278,6 +278,64 @@ def test_wide_samples_bit_exact(torch_cuda, bpc, dtype, nch, interp):
     fixca.lib.fixca_release_cache()
 
 
+@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("shape", [(157, 61, 3), (361, 140, 4), (1201, 77, 4), (240, 300, 3)], ids=str)
+def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
+    """k_wcol (fixca_wide.hip): odd widths, several strips and tiles, scale steps inside a tile, RGB and
+    RGBA, every sample type: identical to the oracle bit for bit, linear and cubic, full image and row range"""
+    torch = torch_cuda
+    w, h, nch = shape
+    sb = abs(bpc)
+    img = _wide_image(dtype, w, h, nch, 1300 + abs(bpc) + w)
+    for interp, kw in ((2, dict(blue=3.3, red=-2.4, lens_x=w * 0.3, lens_y=h * 0.4, x_blue=1.5, y_red=-2.25)),
+                       (1, dict(blue=-7.5, red=9.0, lens_x=-1, lens_y=h - 1, y_blue=11.0, x_red=-13.5)),
+                       (2, dict(lens_x=w // 2, lens_y=h // 2, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0))):
+        p = fixca.make_params(interpolation=interp, **kw)
+        kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
+        assert kid == 7, desc
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
+        src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+        dst = torch.zeros_like(src)
+        fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+        torch.cuda.synchronize()
+        assert dst.cpu().numpy().view(dtype).reshape(h, w, nch).tobytes() == ref.tobytes(), desc
+        part = torch.full_like(src, 0x5A)
+        fixca.fix_ca_region(src, part, w, h, nch * sb, bpc, p, 0, w, 7, h - 3, True)
+        torch.cuda.synchronize()
+        got = part.cpu().numpy()
+        assert got[7:h - 3].tobytes() == ref.view(np.uint8).reshape(h, w, nch * sb)[7:h - 3].tobytes()
+        assert np.all(got[:7] == 0x5A) and np.all(got[h - 3:] == 0x5A)
+
+
+@pytest.mark.parametrize("bpc,dtype", [(1, np.uint8)] + WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("nch", [3, 4])
+@pytest.mark.parametrize("interp", [0, 2])
+def test_preview_window_and_down_conversion(torch_cuda, bpc, dtype, nch, interp):
+    """preview_update()'s pixels (fix-ca.c:617-679): rows of the window corrected with show_progress
+    FALSE (centre lines drawn), window cropped, samples wider than 8 bits converted by
+    get_pixel -> set_pixel(.., 1) -- including what the reference's x86 build does with floats
+    outside [0,1] (green/alpha are copied, None copies red/blue too)"""
+    w, h = 333, 120
+    x, y, pw, ph = 41, 17, 200, 75
+    img = synth.noise_image(77 + nch, w, h, nch) if bpc == 1 else _wide_image(dtype, w, h, nch, 1700 + abs(bpc) + nch)
+    if bpc < 0:
+        img = (img * 4 - 1.5).astype(dtype)                  # plenty of values below 0 and above 1
+        img[20, 50] = [np.nan, 3e12, -3e12][:3] + [np.inf][:nch - 3]
+    p = fixca.make_params(blue=2.5, red=-1.75, lens_x=150, lens_y=50, interpolation=interp, y_blue=1.5)
+    po = pyoracle.make_params(**p.as_dict())
+    full = pyoracle.region(img, po, bpc=bpc, y1=y, y2=y + ph, show_progress=0)
+    ref = pyoracle.preview(full, bpc, x, y, pw, ph)
+    got = fixca.preview(img, p, bpc, x, y, pw, ph)
+    if bpc == 1:
+        got = got.reshape(ref.shape)
+        mx, _ = diff_stats(got, ref)
+        assert mx <= (0 if interp == 0 else TOL_LSB)          # the 8-bit fast kernels: +-1 LSB; the crop itself is exact
+        assert np.array_equal(got[..., 1], ref[..., 1])
+    else:
+        assert np.array_equal(got, ref)
+    fixca.lib.fixca_release_cache()
+
+
 # ---- the host-pointer entry (what the plug-in calls) --------------------------------
 
 @pytest.mark.parametrize("interp", [0, 1, 2])
@@ -345,6 +403,19 @@ def test_device_entry_rejects_bad_calls(torch_cuda):
 
 
 # ---- batch entry and full-size configurations -------------------------------------------
+
+def test_device_noise_matches_synth(torch_cuda):
+    """fixca_noise_device writes SURVEY §8d's noise(seed) byte for byte (odd sizes included)"""
+    torch = torch_cuda
+    for seed, n in ((1, 8), (0xF1CA0001, 6000 * 40 * 4), (0xF1CA1000 + 511, 12345), (2 ** 64 - 5, 64)):
+        t = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+        fixca.noise_fill(t[:n], seed)
+        torch.cuda.synchronize()
+        got = t.cpu().numpy()
+        assert np.array_equal(got[:n], synth.noise_bytes(seed, n)), (seed, n)
+        assert np.all(got[n:] == 0)
+    assert synth.noise_bytes(1, 8).tolist() == [193, 92, 2, 137, 236, 45, 10, 145]
+
 
 def test_batch_entry(torch_cuda):
     torch = torch_cuda
@@ -465,7 +536,7 @@ def test_batch_full_size_images_0_31_32_last(torch_cuda):
 
 
 def test_batch_entry_more_images_than_one_launch_takes(torch_cuda):
-    """the row-rolling kernel takes 64 images per launch: 70 images = 2 launches"""
+    """the row-rolling kernel takes 32 images per launch: 70 images = 3 launches"""
     torch = torch_cuda
     p = fixca.make_params(blue=0.5, red=-0.4, lens_x=300, lens_y=20, interpolation=2, x_blue=1.25, y_red=-0.5)
     assert fixca.plan(512, 40, 4, 1, p)[0] == 6

@@ -110,6 +110,30 @@ def test_fix_ca_fails_loudly_without_gpu(host):
     assert host.fix_ca(ctypes.byref(d), ctypes.byref(p)) == -1          # empty selection
 
 
+def test_preview_pixels_arguments_and_no_gpu(host):
+    """fixca_preview_pixels (preview_update's pixel work, fix-ca.c:647-671): argument errors are reported
+    without a GPU; with valid arguments and no GPU the call fails loudly (-1, E_NODEVICE)"""
+    host.fixca_preview_pixels.argtypes = [ctypes.POINTER(Drawable), ctypes.POINTER(fixca.FixCaParams)] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    img = np.zeros((16, 32, 4), np.uint16)
+    prev = np.zeros((8, 10, 4), np.uint8)
+    d = Drawable(img.ctypes.data, 32, 16, 8, 2, 0, 0, 32, 16)
+    p = fixca.make_params(blue=1, lens_x=16, lens_y=8)
+    assert host.fixca_preview_pixels(ctypes.byref(d), ctypes.byref(p), 30, 2, 10, 8, prev.ctypes.data) == -1     # window leaves the image
+    assert b"outside" in fixca.lib.fixca_last_error()
+    p.saturation = 20.0
+    assert host.fixca_preview_pixels(ctypes.byref(d), ctypes.byref(p), 3, 2, 10, 8, prev.ctypes.data) == -1      # saturate(): refused
+    assert b"saturation" in fixca.lib.fixca_last_error()
+    p.saturation = 0.0
+    d.bpc = -99
+    assert host.fixca_preview_pixels(ctypes.byref(d), ctypes.byref(p), 3, 2, 10, 8, prev.ctypes.data) == -1
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d.bpc = 2
+    assert host.fixca_preview_pixels(ctypes.byref(d), ctypes.byref(p), 3, 2, 10, 8, prev.ctypes.data) == -1
+    assert fixca.lib.fixca_preview_host(img.ctypes.data, prev.ctypes.data, 32, 16, 8, 2, ctypes.byref(p), 3, 2, 10, 8) == fixca.E_NODEVICE
+
+
 def test_cli_usage_and_no_gpu(tmp_path):
     assert subprocess.run([CLI], capture_output=True).returncode == 2
     import torch

@@ -1,6 +1,8 @@
 """The CPU oracle against every golden vector the survey recorded from the
 reference's own fix_ca_region (60 small cases; §8(d): the
 full-size configs, marked slow) and against its own structural properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -74,3 +76,14 @@ def test_refuses_undefined_domain():
     img = synth.noise_image(3, 16, 16, 4)
     with pytest.raises(ValueError):        # max_dim + amount <= 0: the reference divides by <= 0
         pyoracle.region(img, pyoracle.make_params(blue=-30.0, lens_x=8, lens_y=8))
+
+
+def test_reciprocal_division_is_exact(tmp_path):
+    """k_wcol replaces get_pixel's division by 2^n - 1 (fix-ca.c:720-726) with multiply + two FMAs; that
+    is the correctly rounded quotient for every u8, u16 and u32 sample value (exhaustive, ~10 s)."""
+    import subprocess
+    exe = tmp_path / "divcheck"
+    src = os.path.join(os.path.dirname(__file__), "c", "divcheck.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.split() == ["u8", "0", "u16", "0", "u32", "0"], out.stdout
