@@ -4,8 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gimp-fix-ca_amd"))
 import torch, fixca
 W, H = 6000, 4000
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, bpc, nch in (("RGBA u16", 2, 4), ("RGBA float", -4, 4), ("RGBA u32", 4, 4), ("RGBA double", -8, 4), ("RGB u16", 2, 3), ("RGB float", -4, 3)):
-    for interp in (2, 1):
+    if ONLY and ONLY not in name:
+        continue
+    for interp in ((2,) if ONLY else (2, 1)):
         p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=interp)
         sb = abs(bpc)
         B = 4
@@ -17,7 +20,7 @@ for name, bpc, nch in (("RGBA u16", 2, 4), ("RGBA float", -4, 4), ("RGBA u32", 4
         if bpc == -8:
             raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(B, H, W, nch * sb)
         dst = torch.empty_like(raw)
-        for kern, kname in ((fixca.KERNEL_AUTO, "auto"), (fixca.KERNEL_EXACT, "exact")):
+        for kern, kname in (((fixca.KERNEL_AUTO, "auto"),) if ONLY else ((fixca.KERNEL_AUTO, "auto"), (fixca.KERNEL_EXACT, "exact"))):
             desc = fixca.plan(W, H, nch * sb, bpc, p, kernel=kern)[1]
             for i in range(B):
                 fixca.fix_ca_region(raw[i], dst[i], W, H, nch * sb, bpc, p, 0, W, 0, H, True, kern)
