@@ -59,7 +59,7 @@ extern "C" {
  */
 FIXCA_API int fixca_region_host(const unsigned char *src, unsigned char *dst,
                                 int orig_width, int orig_height, int bytes, int bpc,
-                                const FixCaParams *params,
+                                const FIXCA_PARAMS_T *params,
                                 int x1, int x2, int y1, int y2, int show_progress);
 
 /*
@@ -69,7 +69,7 @@ FIXCA_API int fixca_region_host(const unsigned char *src, unsigned char *dst,
  */
 FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
                                   int orig_width, int orig_height, int bytes, int bpc,
-                                  const FixCaParams *params,
+                                  const FIXCA_PARAMS_T *params,
                                   int x1, int x2, int y1, int y2, int show_progress,
                                   unsigned flags, void *stream);
 
@@ -81,7 +81,7 @@ FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
  */
 FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, int n_images,
                                  int orig_width, int orig_height, int bytes, int bpc,
-                                 const FixCaParams *params, unsigned flags, void *stream);
+                                 const FIXCA_PARAMS_T *params, unsigned flags, void *stream);
 
 /*
  * Which kernel the planner picks for a call, without launching anything (usable
@@ -90,14 +90,14 @@ FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, i
  * negative FIXCA_E_* if the call itself would be refused.
  */
 FIXCA_API int fixca_plan_describe(int orig_width, int orig_height, int bytes, int bpc,
-                                  const FixCaParams *params, int x1, int x2, int y1, int y2,
+                                  const FIXCA_PARAMS_T *params, int x1, int x2, int y1, int y2,
                                   int show_progress, unsigned flags, char *buf, size_t buflen);
 
 /*
  * Validates a parameter block the way run() does for non-interactive calls
  * (fix-ca.c:279-295): every amount within ±FIXCA_INPUT_MAX, interpolation 0..2.
  */
-FIXCA_API int fixca_params_check(const FixCaParams *params);
+FIXCA_API int fixca_params_check(const FIXCA_PARAMS_T *params);
 
 /* ---- device plumbing for C hosts (the plug-in has no torch) ------------- */
 FIXCA_API int   fixca_device_count(void);             /* >= 0, or FIXCA_E_HIP         */
@@ -132,7 +132,7 @@ FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_hos
  */
 FIXCA_API int fixca_preview_host(const unsigned char *src, unsigned char *prev,
                                  int orig_width, int orig_height, int bytes, int bpc,
-                                 const FixCaParams *params, int x, int y, int width, int height);
+                                 const FIXCA_PARAMS_T *params, int x, int y, int width, int height);
 FIXCA_API int fixca_preview_device(const void *d_img, void *d_prev,
                                    int orig_width, int orig_height, int bytes, int bpc,
                                    int x, int y, int width, int height, void *stream);
@@ -153,7 +153,7 @@ FIXCA_API int fixca_noise_device(void *d_dst, size_t nbytes, unsigned long long 
  */
 FIXCA_API int fixca_time_launches(const void *const *d_src, void *const *d_dst, int n_pairs,
                                   int launches, int orig_width, int orig_height, int bytes,
-                                  int bpc, const FixCaParams *params, unsigned flags,
+                                  int bpc, const FIXCA_PARAMS_T *params, unsigned flags,
                                   void *stream, double *ms_per_launch);
 
 /*
@@ -171,7 +171,7 @@ FIXCA_API int         fixca_abi_version(void);         /* 1                     
  * {ncols, rows, nbig, big_blocks, L, Hb, pool_chunks, pool_waves, pool_blocks, th} for a chip with
  * `resident` wave slots (no GPU needed).  fixca_debug_host_cache: the calling thread's cached
  * device images of fixca_region_host. */
-FIXCA_API int  fixca_debug_sched(int orig_width, int orig_height, int bytes, const FixCaParams *params,
+FIXCA_API int  fixca_debug_sched(int orig_width, int orig_height, int bytes, const FIXCA_PARAMS_T *params,
                                  int n_images, int resident, int *out10);
 FIXCA_API void fixca_debug_host_cache(void **src_image, void **dst_image, size_t *nbytes);
 

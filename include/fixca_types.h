@@ -21,6 +21,18 @@ enum {
 	FIXCA_INTERP_CUBIC  = 2
 };
 
+/*
+ * A translation unit that declares FixCaParams itself -- the plug-in's fix-ca.c does
+ * (fix-ca.c:70-82) -- defines FIXCA_TYPES_NO_PARAMS before including this header: the struct is
+ * then not declared here and the entry points take `const struct FixCaParams_ *`, an opaque
+ * type, so the plug-in passes a cast pointer to its own (byte-identical) struct
+ * (tools/gimp_box/apply_binding.py).
+ */
+#ifdef FIXCA_TYPES_NO_PARAMS
+struct FixCaParams_;
+#define FIXCA_PARAMS_T struct FixCaParams_
+#else
+#define FIXCA_PARAMS_T FixCaParams
 typedef struct FixCaParams {
 	double blue;            /* lateral blue amount, pixels at max_dim      */
 	double red;             /* lateral red amount                          */
@@ -34,6 +46,7 @@ typedef struct FixCaParams {
 	double y_blue;
 	double y_red;
 } FixCaParams;
+#endif
 
 /* fix-ca.c:63-67.  INPUT_MAX is SOURCE_ROWS/4 == 30 wherever it is used. */
 #define FIXCA_SOURCE_ROWS 120
@@ -46,10 +59,12 @@ typedef struct FixCaParams {
 }
 #endif
 
+#ifndef FIXCA_TYPES_NO_PARAMS
 #if defined(__cplusplus)
 static_assert(sizeof(FixCaParams) == 80, "FixCaParams must stay 80 bytes");
 #else
 _Static_assert(sizeof(FixCaParams) == 80, "FixCaParams must stay 80 bytes");
+#endif
 #endif
 
 #endif /* FIXCA_TYPES_H */

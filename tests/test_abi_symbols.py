@@ -4,6 +4,7 @@ without a GPU (no CPU fallback)."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -135,3 +136,34 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(fixca.FixCaError) as e:
         fixca.fix_ca_image(img, fixca.make_params(blue=1, lens_x=16, lens_y=8))
     assert e.value.code in (fixca.E_NODEVICE, fixca.E_HIP)
+
+
+def test_gimp_box_binding(tmp_path):
+    """tools/gimp_box: the binding compiles next to the plug-in's own FixCaParams declaration, and the
+    patcher puts it at the two anchors of the reference's fix-ca.c and nowhere else (skipped where the
+    reference tree is absent, e.g. on the GPU box)"""
+    import subprocess
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                           os.path.join(root, "tests", "c", "binding_check.c"), "-o", str(tmp_path / "b.o")])
+    ref = "/root/reference/fix-ca.c"
+    if not os.path.exists(ref):
+        pytest.skip("no reference tree here")
+    work = tmp_path / "fix-ca.c"
+    shutil.copyfile(ref, work)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gimp_box", "apply_binding.py"), str(work), root])
+    old = open(ref, encoding="utf-8").read().split("\n")
+    new = open(work, encoding="utf-8").read().split("\n")
+    import difflib
+    ops = [op for op in difflib.SequenceMatcher(None, old, new, autojunk=False).get_opcodes() if op[0] != "equal"]
+    assert [op[0] for op in ops] == ["insert", "insert"] and len(new) == len(old) + 6      # two insertions, nothing removed or changed
+    i_inc = new.index("#include <fixca_hip.h>")
+    assert "gimpui.h" in new[i_inc - 2]
+    i_call = next(i for i, l in enumerate(new) if "fixca_region_host" in l)
+    assert new[i_call - 2].strip() == "{"                       # first statement of the definition ...
+    assert any("fix_ca_region" in l for l in new[i_call - 8:i_call - 2])      # ... of fix_ca_region
+    assert sum("fixca_region_host" in l for l in new) == 1
+    # running it twice changes nothing more
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gimp_box", "apply_binding.py"), str(work), root])
+    assert open(work, encoding="utf-8").read().split("\n") == new

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")[:60]
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:60]
 
 
 def traffic_json(d, kernel_prefix, out_path):
@@ -43,9 +43,10 @@ def main(d):
         for r in csv.DictReader(open(f)):
             durs[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         print("== kernel trace:", os.path.relpath(f, d))
-        print("%-62s %6s %10s %10s %10s %10s" % ("kernel", "calls", "mean_us", "median_us", "min_us", "max_us"))
+        print("%-62s %6s %10s %10s %10s %10s %10s" % ("kernel", "calls", "mean_us", "median_us", "stdev_us", "min_us", "max_us"))
         for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
-            print("%-62s %6d %10.2f %10.2f %10.2f %10.2f" % (k, len(v), statistics.mean(v), statistics.median(v), min(v), max(v)))
+            print("%-62s %6d %10.2f %10.2f %10.2f %10.2f %10.2f" % (k, len(v), statistics.mean(v), statistics.median(v),
+                                                                   statistics.stdev(v) if len(v) > 1 else 0.0, min(v), max(v)))
     for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
