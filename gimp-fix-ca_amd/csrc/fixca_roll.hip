@@ -74,6 +74,10 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
 #define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
 #define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
+#ifndef ROLL_NRB
+#define ROLL_NRB    4                   /* output rows per block of the regular path.  2 (135 instead of 166 VGPRs for RGB8
+                                         * cubic) measured 1.5 points slower, 2 with 4 waves per SIMD forced 3.5 points slower */
+#endif
 #ifndef RDEPTH
 #define RDEPTH      6                   /* source rows kept in flight beyond the newest row in use */
 #endif
@@ -433,7 +437,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	constexpr int T = TAPS;
 	constexpr int NP = NW + 3;                      /* pixels of the 8 that carry weight */
 	STAMP(0);                                       /* everything outside blocks */
-	roll_fetch(st, b.keep, NR == 4 ? b.need4 : b.need1);
+	roll_fetch(st, b.keep, NR > 1 ? b.need4 : b.need1);     /* need4 covers rows y .. y+3: right for 4, safe for 2 */
 	STAMP(1);                                       /* fetch: DMA issue + wait */
 	const int nR = b.rb[0] + T - 1, nB = b.rb[1] + T - 1;   /* newest row of output row y */
 
@@ -600,14 +604,15 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 		int r = 0;
 		while (r < nrows) {
 			const int y = Y0 + r;
-			const bool four = r > 0 && r + 3 < nrows && (b.reg4 & 0xF) == 0xF;
+			constexpr int NRB = ROLL_NRB, RMASK = (1 << NRB) - 1;
+			const bool four = r > 0 && r + NRB - 1 < nrows && (b.reg4 & RMASK) == RMASK;
 			const bool one = r > 0 && (b.reg4 & 1);      /* tails and rows next to an irregular one */
-			const int step = four ? 4 : 1;
+			const int step = four ? NRB : 1;
 			/* the next descriptor is requested before this block's work: its scalar load has the
 			 * whole block to come back */
 			RollBlock bn = b;
 			if (r + step < nrows) bn = load_block(blocks, y + step);
-			if (four)     roll_block<TAPS, P2, NW, 4>(st, wx, b, bn, roww, y);
+			if (four)     roll_block<TAPS, P2, NW, NRB>(st, wx, b, bn, roww, y);
 			else if (one) roll_block<TAPS, P2, NW, 1>(st, wx, b, bn, roww, y);
 			else          roll_row_any<TAPS, P2, NW>(st, wx, b, roww, y);
 			r += step;

@@ -24,13 +24,13 @@
  * agreement depends on it.  Compile with -ffp-contract=off and no -march that
  * would license FMA contraction.
  *
- * Parity pin (see oracle/README.md): the reference cannot be compiled in this
- * image (it needs <libgimp/gimp.h>, GEGL, babl, GTK; writing stand-ins for
- * them is not allowed), so oracle/_ref is not built.  The pin is the table of
- * md5 vectors SURVEY.md Appendix C / §8(d) records from the reference's own
- * fix_ca_region (60 + 7 cases), checked by tests/test_oracle_golden.py.  The
- * reference's single own fixture, tests/test1.md5, needs GIMP's JPEG loader
- * and BMP writer and is not checkable here.
+ * PARITY UNPINNED (see oracle/README.md): the reference cannot be compiled in
+ * this image (it needs <libgimp/gimp.h>, GEGL, babl, GTK; writing stand-ins for
+ * them is not allowed), so oracle/_ref is not built, and the reference's single
+ * own fixture, tests/test1.md5, needs GIMP's JPEG loader and BMP writer.  What
+ * the oracle is checked against is the table of md5 vectors SURVEY.md Appendix
+ * C / §8(d) records (60 + 7 cases, tests/test_oracle_golden.py): a consistency
+ * check, not a reference-held pin.
  */
 #include <limits.h>
 #include <math.h>
