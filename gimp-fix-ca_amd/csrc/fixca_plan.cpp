@@ -431,23 +431,21 @@ void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, int 
 	sc->rows = rows;
 	sc->th = pl->th;
 	long long nbig = 0, L = 0, Hb = 0;
-	/* Big pieces are OFF unless asked for (FIXCA_DEBUG_RESIDENT under FIXCA_DEBUG): in the skeleton
-	 * they gain 4 - 5 points, in k_roll itself they lose 5 - 7 (35.0 -> 37.4 us per image, with and
-	 * without the filter arithmetic), not yet understood; the decode and tests stay so that the
-	 * comparison can be repeated. */
 	if (resident > 0 && n_images > 1 && rows >= 8 * pl->th) {
-		/* 90 % of the slots: a piece that found no slot would start when the first piece ends and
-		 * double the launch time, so the count stays clear of the occupancy estimate */
-		nbig = (long long)resident * 9 / 10;
-		Hb = ((long long)rows * 3 / 4) & ~3LL;          /* three quarters of the rows */
-		const long long total = (long long)sc->ncols * Hb;
-		L = ((total + nbig - 1) / nbig + 3) & ~3LL;
+		/* at most 90 % of the slots: a piece that found no slot would start when the first piece
+		 * ends and double the launch time, so the count stays clear of the occupancy estimate */
+		const long long nseg = ((long long)resident * 9 / 10) / sc->ncols;
+		/* a slot's fair share of the launch is ncols * rows / resident rows; a big piece gets 85 % of
+		 * that, so that a slow wave, CU or XCD still finishes its piece before the pool runs dry */
+		L = ((long long)sc->ncols * rows * 85 / 100 / resident) & ~3LL;
+		if (nseg >= 1 && L * nseg > (long long)rows * 9 / 10) L = ((long long)rows * 9 / 10 / nseg) & ~3LL;
 		/* pieces worth having: several pool tiles long, and short enough for k_roll's 32-bit
 		 * offsets inside a wave's rows (the halo is at most 2 * FIXCA_SOURCE_ROWS more) */
-		if (L < 4 * pl->th || (L + 2 * FIXCA_SOURCE_ROWS) * (long long)g->W * g->bpp > (1LL << 31)) {
-			nbig = 0; L = 0; Hb = 0;
+		if (nseg < 1 || L < 4 * pl->th || (L + 2 * FIXCA_SOURCE_ROWS) * (long long)g->W * g->bpp > (1LL << 31)) {
+			L = 0;
 		} else {
-			nbig = (total + L - 1) / L;
+			nbig = nseg * sc->ncols;
+			Hb = nseg * L;
 		}
 	}
 	sc->nbig = (int)nbig;

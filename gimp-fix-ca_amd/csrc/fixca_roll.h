@@ -61,27 +61,26 @@ struct RollBatch {
  * A column is one strip of one image; the launch has ncols = n_images * nstrips of them, each
  * `rows` output rows tall.  Two kinds of tile, both handled by one wave:
  *
- *  - BIG pieces.  The first Hb rows of all columns, laid end to end (column 0's rows, then column
- *    1's, ...), are cut into nbig pieces of L rows; piece k is workgroup k.  There are fewer big
- *    pieces than wave slots on the chip, so all of them are resident from the start and each
- *    streams through its rows with no halo re-read and no pipeline restart (a piece that crosses
- *    a column boundary restarts once there).  Their work is about three quarters of the launch,
- *    so they finish well before the end.
+ *  - BIG pieces (optional).  The first Hb = nseg * L rows of every column are cut into nseg pieces
+ *    of L rows.  There are fewer big pieces than wave slots on the chip, so all of them are resident
+ *    from the start and each streams through its rows with no halo re-read and no pipeline restart.
+ *    Piece t (after the XCD remap of the workgroup index) is segment t / ncols of column t % ncols:
+ *    the pieces that work on the same rows of neighbouring strips at the same time have consecutive
+ *    t, so they share an XCD and its L2 serves the columns their source windows have in common.
+ *    They are sized to finish at about 85 % of the launch.
  *  - POOL tiles: the remaining rows [Hb, rows) of every column in chunks of `th` rows, in the
  *    workgroups after the big ones.  The dispatcher hands them to whichever slots are free: the
- *    few slots the big pieces left over at first, every slot once the big pieces are done.  They
- *    absorb the speed differences between waves, CUs and XCDs and keep the tail of the launch
- *    short.
+ *    slots the big pieces left over at first, every slot once the big pieces are done.  They
+ *    absorb the speed differences between waves, CUs and XCDs and keep the tail of the launch short.
  *
- * nbig == 0 (one image, or a geometry too small for pieces worth having): pool tiles only,
- * Hb == 0, which is the schedule of round 1. */
+ * nbig == 0: pool tiles only, Hb == 0, which is the schedule of round 1. */
 struct RollSched {
 	int ncols;          /* n_images * nstrips                                                     */
 	int rows;           /* y2 - y1                                                                */
-	int nbig;           /* big pieces (0: none)                                                   */
+	int nbig;           /* big pieces = ncols * nseg (0: none)                                    */
 	int big_blocks;     /* workgroups reserved for them: nbig rounded up to a multiple of 8        */
 	int L;              /* rows per big piece, a multiple of 4                                    */
-	int Hb;             /* rows of every column that belong to big pieces, a multiple of 4         */
+	int Hb;             /* rows of every column that belong to big pieces = nseg * L              */
 	int pool_chunks;    /* pool chunks per column: ceil((rows - Hb) / th)                          */
 	int pool_waves;     /* pool tiles per image: nstrips * pool_chunks                             */
 	int pool_blocks;    /* workgroups per image for them: pool_waves rounded up to a multiple of 8 */

@@ -649,18 +649,12 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 	 * (fixca_roll.h).  Everything below is wave-uniform scalar arithmetic on kernel arguments. */
 	const int bx = blockIdx.x;
 	if (bx < sc.big_blocks) {
-		/* a big piece: rows [f0, f1) of the columns' first Hb rows laid end to end */
-		if (bx >= sc.nbig) return;
-		long long f0 = (long long)bx * sc.L;
-		const long long f1 = min(f0 + sc.L, (long long)sc.ncols * sc.Hb);
-		while (f0 < f1) {
-			const int col = (int)(f0 / sc.Hb);
-			const int yy = (int)(f0 - (long long)col * sc.Hb);
-			const int n = (int)min((long long)(sc.Hb - yy), f1 - f0);
-			const int img = col / pl.nstrips;
-			roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, col - img * pl.nstrips, g.y1 + yy, n);
-			f0 += n;
-		}
+		/* a big piece: segment t / ncols of column t % ncols (RollSched) */
+		const int t = xcd_remap(bx, sc.big_blocks);
+		if (t >= sc.nbig) return;
+		const int seg = t / sc.ncols, col = t - seg * sc.ncols;
+		const int img = col / pl.nstrips;
+		roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, col - img * pl.nstrips, g.y1 + seg * sc.L, sc.L);
 		return;
 	}
 	/* a pool tile.  Workgroups [k * pool_blocks, (k + 1) * pool_blocks) after the big ones are image

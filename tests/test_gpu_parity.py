@@ -490,15 +490,14 @@ def test_batch_entry_replays_from_a_hip_graph(torch_cuda):
 @pytest.mark.parametrize("interp", [0, 1, 2])
 def test_batch_two_level_schedule(torch_cuda, monkeypatch, channels, interp):
     """big pieces + pool tiles (RollSched): pretend the chip holds 20 waves so that 8 small images are
-    scheduled the way 16+ full-size ones are: 18 big pieces of 400 rows that cross column
-    boundaries (Hb = 300) and pool tiles below them"""
+    scheduled the way 16+ full-size ones are: big pieces above, pool tiles below"""
     torch = torch_cuda
-    monkeypatch.setenv("FIXCA_DEBUG_RESIDENT", "20")
+    monkeypatch.setenv("FIXCA_DEBUG_RESIDENT", "60")
     w, h, n = 768, 400, 8
     p = fixca.make_params(blue=0.9, red=-0.7, lens_x=300, lens_y=150, interpolation=interp, y_red=-0.5)
     assert fixca.plan(w, h, channels, 1, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)[0] == 6
-    sc = fixca.debug_sched(w, h, channels, p, n, 20)
-    assert sc["nbig"] > 0 and sc["L"] > sc["Hb"] > 0 and sc["pool_chunks"] > 0, sc
+    sc = fixca.debug_sched(w, h, channels, p, n, 60)
+    assert sc["nbig"] > 0 and sc["nbig"] % sc["ncols"] == 0 and sc["Hb"] > 0 and sc["pool_chunks"] > 0, sc
     imgs = [synth.noise_image(900 + i, w, h, channels) for i in range(n)]
     srcs = [torch.from_numpy(a).cuda() for a in imgs]
     dsts = [torch.full_like(s, 0x55) for s in srcs]
