@@ -455,6 +455,8 @@ void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, int 
 	sc->pool_chunks = (int)((rows - Hb + pl->th - 1) / pl->th);
 	sc->pool_waves = pl->nstrips * sc->pool_chunks;
 	sc->pool_blocks = (sc->pool_waves + 7) & ~7;
+	sc->total = n_images * sc->pool_waves;
+	sc->qsize = (sc->total + 7) / 8;
 }
 
 /* test hook (CPU): the schedule as numbers */

@@ -85,6 +85,10 @@ struct RollSched {
 	int pool_waves;     /* pool tiles per image: nstrips * pool_chunks                             */
 	int pool_blocks;    /* workgroups per image for them: pool_waves rounded up to a multiple of 8 */
 	int th;             /* rows per pool tile                                                     */
+	/* persistent launch (k_roll_p): the launch's pool tiles, numbered image by image, chunk by chunk,
+	 * strip by strip, are split into 8 contiguous queues of qsize tiles, one per XCD */
+	int total;          /* n_images * pool_waves                                                  */
+	int qsize;          /* ceil(total / 8)                                                        */
 };
 
 /* fixca_plan.cpp: resident = wave slots of the chip for this kernel (waves per CU x CUs), 0 = unknown */
