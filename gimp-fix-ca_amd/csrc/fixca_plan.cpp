@@ -415,52 +415,22 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	return false;
 }
 
-/* The two-level tile schedule of one k_roll launch (RollSched, fixca_roll.h).
- *
- * Measured on MI355X (tools/kbench2.hip, the kernel's data movement without its arithmetic, 16 images
- * of 6000x4000): dynamically dispatched tiles of 33 rows 69.6 - 70.8 % of the HBM peak, big pieces
- * on 87 % of the slots covering 50 - 80 % of the rows plus pool tiles 72.9 - 75.0 %, flat over that
- * range.  A launch of big pieces only is slower than either whenever the pieces do not divide
- * evenly over the CUs or one wave runs slow (the launch ends with its slowest wave), which is what
- * the pool prevents. */
-void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, int resident, RollSched *sc)
+/* The tile schedule of one k_roll launch (RollSched, fixca_roll.h) */
+void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, RollSched *sc)
 {
 	memset(sc, 0, sizeof *sc);
 	const int rows = g->y2 - g->y1;
 	sc->ncols = n_images * pl->nstrips;
 	sc->rows = rows;
 	sc->th = pl->th;
-	long long nbig = 0, L = 0, Hb = 0;
-	if (resident > 0 && n_images > 1 && rows >= 8 * pl->th) {
-		/* at most 90 % of the slots: a piece that found no slot would start when the first piece
-		 * ends and double the launch time, so the count stays clear of the occupancy estimate */
-		const long long nseg = ((long long)resident * 9 / 10) / sc->ncols;
-		/* a slot's fair share of the launch is ncols * rows / resident rows; a big piece gets 85 % of
-		 * that, so that a slow wave, CU or XCD still finishes its piece before the pool runs dry */
-		L = ((long long)sc->ncols * rows * 85 / 100 / resident) & ~3LL;
-		if (nseg >= 1 && L * nseg > (long long)rows * 9 / 10) L = ((long long)rows * 9 / 10 / nseg) & ~3LL;
-		/* pieces worth having: several pool tiles long, and short enough for k_roll's 32-bit
-		 * offsets inside a wave's rows (the halo is at most 2 * FIXCA_SOURCE_ROWS more) */
-		if (nseg < 1 || L < 4 * pl->th || (L + 2 * FIXCA_SOURCE_ROWS) * (long long)g->W * g->bpp > (1LL << 31)) {
-			L = 0;
-		} else {
-			nbig = nseg * sc->ncols;
-			Hb = nseg * L;
-		}
-	}
-	sc->nbig = (int)nbig;
-	sc->big_blocks = (int)((nbig + 7) & ~7LL);
-	sc->L = (int)L;
-	sc->Hb = (int)Hb;
-	sc->pool_chunks = (int)((rows - Hb + pl->th - 1) / pl->th);
+	sc->pool_chunks = (rows + pl->th - 1) / pl->th;
+	if (sc->pool_chunks < 1) sc->pool_chunks = 1;
 	sc->pool_waves = pl->nstrips * sc->pool_chunks;
 	sc->pool_blocks = (sc->pool_waves + 7) & ~7;
-	sc->total = n_images * sc->pool_waves;
-	sc->qsize = (sc->total + 7) / 8;
 }
 
 /* test hook (CPU): the schedule as numbers */
-extern "C" __attribute__((visibility("default"))) int fixca_debug_sched(int W, int H, int bytes, const FixCaParams *p, int n_images, int resident, int *out10)
+extern "C" __attribute__((visibility("default"))) int fixca_debug_sched(int W, int H, int bytes, const FixCaParams *p, int n_images, int *out6)
 {
 	FixcaGeom g;
 	FixcaPlan pl;
@@ -470,9 +440,9 @@ extern "C" __attribute__((visibility("default"))) int fixca_debug_sched(int W, i
 	if (rc) return rc;
 	if (pl.kernel != FIXCA_K_ROLL) return fixca_fail(FIXCA_E_UNSUPPORTED, "not a k_roll geometry");
 	RollSched sc;
-	roll_make_sched(&g, &pl, n_images, resident, &sc);
-	const int v[10] = { sc.ncols, sc.rows, sc.nbig, sc.big_blocks, sc.L, sc.Hb, sc.pool_chunks, sc.pool_waves, sc.pool_blocks, sc.th };
-	memcpy(out10, v, sizeof v);
+	roll_make_sched(&g, &pl, n_images, &sc);
+	const int v[6] = { sc.ncols, sc.rows, sc.pool_chunks, sc.pool_waves, sc.pool_blocks, sc.th };
+	memcpy(out6, v, sizeof v);
 	return FIXCA_OK;
 }
 

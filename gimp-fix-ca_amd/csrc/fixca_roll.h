@@ -56,44 +56,30 @@ struct RollBatch {
 	uint8_t       *dst[ROLL_BATCH_MAX];
 };
 
-/* The tile schedule of one launch (a kernel argument, built by roll_make_sched in fixca_plan.cpp).
+/* The tile schedule of one launch (a kernel argument, built by roll_make_sched in fixca_plan.cpp):
+ * every image's rows in chunks of `th`, every chunk in strips; image k's tiles are workgroups
+ * [k * pool_blocks, (k + 1) * pool_blocks), numbered chunk-major and remapped so that each XCD owns
+ * a contiguous range (neighbouring strips and chunks, whose source windows overlap, share an L2).
+ * The dispatcher hands out workgroups in order: image k+1's first waves start in the slots image
+ * k's last waves leave, so there is no fill/drain bubble per image.
  *
- * A column is one strip of one image; the launch has ncols = n_images * nstrips of them, each
- * `rows` output rows tall.  Two kinds of tile, both handled by one wave:
- *
- *  - BIG pieces (optional).  The first Hb = nseg * L rows of every column are cut into nseg pieces
- *    of L rows.  There are fewer big pieces than wave slots on the chip, so all of them are resident
- *    from the start and each streams through its rows with no halo re-read and no pipeline restart.
- *    Piece t (after the XCD remap of the workgroup index) is segment t / ncols of column t % ncols:
- *    the pieces that work on the same rows of neighbouring strips at the same time have consecutive
- *    t, so they share an XCD and its L2 serves the columns their source windows have in common.
- *    They are sized to finish at about 85 % of the launch.
- *  - POOL tiles: the remaining rows [Hb, rows) of every column in chunks of `th` rows, in the
- *    workgroups after the big ones.  The dispatcher hands them to whichever slots are free: the
- *    slots the big pieces left over at first, every slot once the big pieces are done.  They
- *    absorb the speed differences between waves, CUs and XCDs and keep the tail of the launch short.
- *
- * nbig == 0: pool tiles only, Hb == 0, which is the schedule of round 1. */
+ * Round 2 tried two other schedules on top of this one and dropped both (git history: a75aaf2 ..
+ * 601aab9): big static pieces plus a pool of small tiles (+4-5 points in the
+ * data-movement skeleton, +-0 in the kernel once neighbouring strips share an XCD again, -2 on
+ * slow-write boxes), and persistent workgroups pulling tiles from per-XCD queues (+-0 at 32 images
+ * per launch, -2 at 16). */
 struct RollSched {
 	int ncols;          /* n_images * nstrips                                                     */
 	int rows;           /* y2 - y1                                                                */
-	int nbig;           /* big pieces = ncols * nseg (0: none)                                    */
-	int big_blocks;     /* workgroups reserved for them: nbig rounded up to a multiple of 8        */
-	int L;              /* rows per big piece, a multiple of 4                                    */
-	int Hb;             /* rows of every column that belong to big pieces = nseg * L              */
-	int pool_chunks;    /* pool chunks per column: ceil((rows - Hb) / th)                          */
-	int pool_waves;     /* pool tiles per image: nstrips * pool_chunks                             */
-	int pool_blocks;    /* workgroups per image for them: pool_waves rounded up to a multiple of 8 */
-	int th;             /* rows per pool tile                                                     */
-	/* persistent launch (k_roll_p): the launch's pool tiles, numbered image by image, chunk by chunk,
-	 * strip by strip, are split into 8 contiguous queues of qsize tiles, one per XCD */
-	int total;          /* n_images * pool_waves                                                  */
-	int qsize;          /* ceil(total / 8)                                                        */
+	int pool_chunks;    /* chunks per image: ceil(rows / th)                                      */
+	int pool_waves;     /* tiles per image: nstrips * pool_chunks                                 */
+	int pool_blocks;    /* workgroups per image: pool_waves rounded up to a multiple of 8          */
+	int th;             /* rows per tile                                                          */
 };
 
-/* fixca_plan.cpp: resident = wave slots of the chip for this kernel (waves per CU x CUs), 0 = unknown */
+/* fixca_plan.cpp */
 struct FixcaGeom;
 struct FixcaPlan;
-void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, int resident, RollSched *sc);
+void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, RollSched *sc);
 
 #endif

@@ -648,21 +648,8 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 	/* One launch covers a batch of independent images; the schedule is described at RollSched
 	 * (fixca_roll.h).  Everything below is wave-uniform scalar arithmetic on kernel arguments. */
 	const int bx = blockIdx.x;
-	if (bx < sc.big_blocks) {
-		/* a big piece: segment t / ncols of column t % ncols (RollSched) */
-		const int t = xcd_remap(bx, sc.big_blocks);
-		if (t >= sc.nbig) return;
-		const int seg = t / sc.ncols, col = t - seg * sc.ncols;
-		const int img = col / pl.nstrips;
-		roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, col - img * pl.nstrips, g.y1 + seg * sc.L, sc.L);
-		return;
-	}
-	/* a pool tile.  Workgroups [k * pool_blocks, (k + 1) * pool_blocks) after the big ones are image
-	 * k's tiles (pool_blocks is a multiple of 8, so the XCD remap is per image): image k+1's first
-	 * waves start in the slots image k's last waves leave, no fill/drain bubble per image. */
-	const int pb = bx - sc.big_blocks;
-	const int img = pb / sc.pool_blocks;
-	const int bid = pb - img * sc.pool_blocks;
+	const int img = bx / sc.pool_blocks;
+	const int bid = bx - img * sc.pool_blocks;
 	int tile = xcd_remap(bid, sc.pool_blocks);
 #if defined(FIXCA_EXP_ORDER)                    /* timing experiment: tile order */
 	if (pl.ablate == 1) tile = bid;                                  /* consecutive tiles on different XCDs */
@@ -673,45 +660,8 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 	if (pl.ablate == 2) { chunk = tile % sc.pool_chunks; strip = tile / sc.pool_chunks; }          /* strip-major within the XCD range */
 	if (pl.ablate == 3) { tile = bid; chunk = tile % sc.pool_chunks; strip = tile / sc.pool_chunks; }
 #endif
-	const int Y0 = g.y1 + sc.Hb + chunk * sc.th;
+	const int Y0 = g.y1 + chunk * sc.th;
 	roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0));
-}
-
-/* k_roll_p: the same tiles, handed out at run time.
- *
- * The dispatcher deals workgroups to the 8 XCDs in strict rotation, so with one tile per workgroup
- * every XCD gets exactly one eighth of the launch whatever its speed, and the launch ends with the
- * slowest XCD (measured: the XCDs' mean tile times differ by up to 7 %, their finishing times by 4 %
- * of the launch, tools/tilelog.py).  Here only as many workgroups as the chip holds are launched;
- * each takes tiles from its own XCD's queue (a contiguous eighth of the launch's tiles: neighbouring
- * strips and chunks stay on one XCD at about the same time, as with the static remap) until that is
- * empty and then from the others': a fast XCD ends up doing more tiles.  A wave pays one returning
- * atomic per tile (about a microsecond in which its slot would otherwise wait for the dispatcher)
- * and nothing else changes: roll_tile is the same code.  Every wave leaves the loop after it has
- * seen all 8 queues empty. */
-template <int TAPS, bool P2>
-__global__ __launch_bounds__(64) void
-k_roll_p(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc, int *__restrict__ counters)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const int xcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);      /* HW_REG_XCC_ID */
-	for (int k = 0; k < 8; ++k) {
-		const int q = (xcc + k) & 7;
-		const int q0 = q * sc.qsize;
-		const int qn = min(sc.qsize, sc.total - q0);
-		for (;;) {
-			int i = 0;
-			if (threadIdx.x == 0) i = __hip_atomic_fetch_add(&counters[q * 16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			i = __builtin_amdgcn_readfirstlane(i);
-			if (i >= qn) break;
-			const int gidx = q0 + i;
-			const int img = gidx / sc.pool_waves;
-			const int t = gidx - img * sc.pool_waves;
-			const int chunk = t / pl.nstrips, strip = t - chunk * pl.nstrips;
-			const int Y0 = g.y1 + chunk * sc.th;
-			roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0));
-		}
-	}
 }
 
 /* ======================================================================================
@@ -915,44 +865,9 @@ thread_local TableEntry g_tc[TABLE_ENTRIES];
 thread_local unsigned long long g_tick = 0;
 }
 
-#ifndef ROLL_PERSIST_DEFAULT
-#define ROLL_PERSIST_DEFAULT 0
-#endif
-
-/* Tile-queue counters of k_roll_p: 8 queues x 64 bytes, zeroed on the launch stream before every
- * launch.  A small per-thread ring of blocks, so that a launch never zeroes the counters of the
- * previous ones still running on the same stream (they are stream-ordered anyway) or, within 64
- * launches, on another stream of this thread. */
-namespace {
-constexpr int CNT_BLOCKS = 64, CNT_BLOCK_BYTES = 8 * 64;
-struct CounterRing { void *mem = nullptr; int device = -1; int next = 0; };
-thread_local CounterRing g_cnt;
-}
-static hipError_t next_counters(hipStream_t stream, int **out)
-{
-	int dev = 0;
-	hipError_t e = hipGetDevice(&dev);
-	if (e != hipSuccess) return e;
-	if (!g_cnt.mem || g_cnt.device != dev) {
-		if (g_cnt.mem) (void)hipFree(g_cnt.mem);
-		g_cnt.mem = nullptr;
-		e = hipMalloc(&g_cnt.mem, (size_t)CNT_BLOCKS * CNT_BLOCK_BYTES);
-		if (e != hipSuccess) return e;
-		g_cnt.device = dev;
-		g_cnt.next = 0;
-	}
-	char *blk = static_cast<char *>(g_cnt.mem) + (size_t)g_cnt.next * CNT_BLOCK_BYTES;
-	g_cnt.next = (g_cnt.next + 1) % CNT_BLOCKS;
-	e = hipMemsetAsync(blk, 0, CNT_BLOCK_BYTES, stream);
-	if (e != hipSuccess) return e;
-	*out = reinterpret_cast<int *>(blk);
-	return hipSuccess;
-}
-
 extern "C" void ROLL_NAME(fixca_roll_release_tables)(void)
 {
-	if (g_cnt.mem) (void)hipFree(g_cnt.mem);
-	g_cnt = CounterRing();
+
 	for (TableEntry &e : g_tc) {
 		if (e.mem) (void)hipFree(e.mem);
 		if (e.ready) (void)hipEventDestroy(e.ready);
@@ -1039,22 +954,6 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	return hipSuccess;
 }
 
-/* wave slots of the current device for one k_roll instantiation with `lds` bytes of dynamic LDS
- * (waves per CU x CUs); 0 when the runtime cannot tell */
-template <typename K>
-static int resident_slots(K kernel, size_t lds)
-{
-	int dev = 0, cus = 0, per_cu = 0;
-	if (hipGetDevice(&dev) != hipSuccess) return 0;
-	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess) return 0;
-	/* the LDS allocation is the binding limit for this kernel (160 KB per CU); never trust a higher answer */
-	const int by_lds = (int)((160u * 1024u) / (lds ? lds : 1));
-	if (per_cu > by_lds) per_cu = by_lds;
-	if (per_cu < 1 || cus < 1) return 0;
-	return per_cu * cus;
-}
-
 /* n_images images (1 .. ROLL_BATCH_MAX) in one launch */
 extern "C" hipError_t
 ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g,
@@ -1079,50 +978,21 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 		(void)hipFuncSetAttribute((const void *)k_roll<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_roll<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 		(void)hipFuncSetAttribute((const void *)k_roll<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll_p<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll_p<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll_p<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll_p<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll_p<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll_p<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 	});
 	const bool p2 = (pl->ring & (pl->ring - 1)) == 0;
-	auto launch = [&](auto kernel, auto pkernel) -> hipError_t {
-		/* the schedule depends on how many waves of THIS kernel the chip holds at once: asked once
-		 * per instantiation, LDS size and device */
-		static thread_local struct { bool valid; int dev; size_t lds; int slots; } memo;
-		int dev = 0;
-		(void)hipGetDevice(&dev);
-		if (!memo.valid || memo.dev != dev || memo.lds != lds) {
-			memo.slots = resident_slots(kernel, lds);
-			memo.valid = true; memo.dev = dev; memo.lds = lds;
-		}
-		/* big pieces only on request: see roll_make_sched */
-		const int want = fixca_debug_env("FIXCA_DEBUG_RESIDENT", 0, -1, 1 << 20);
-		const int slots = want < 0 ? memo.slots : want;
-		RollSched sc;
-		roll_make_sched(g, pl, n_images, slots, &sc);
-		/* run-time tile queues when the launch is several rounds of the chip's wave slots */
-		const int persist = fixca_debug_env("FIXCA_PERSIST", ROLL_PERSIST_DEFAULT, 0, 1);
-		if (persist && sc.nbig == 0 && memo.slots > 0 && sc.total >= 2 * memo.slots) {
-			int *cnt = nullptr;
-			hipError_t e2 = next_counters(stream, &cnt);
-			if (e2 != hipSuccess) return e2;
-			hipLaunchKernelGGL(pkernel, dim3((unsigned)memo.slots), dim3(64), lds, stream, imgs, *g, *pl, tb, sc, cnt);
-			return hipGetLastError();
-		}
-		const dim3 grid((unsigned)sc.big_blocks + (unsigned)sc.pool_blocks * (unsigned)n_images);
-		hipLaunchKernelGGL(kernel, grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-		return hipGetLastError();
-	};
+	RollSched sc;
+	roll_make_sched(g, pl, n_images, &sc);
+	const dim3 grid((unsigned)sc.pool_blocks * (unsigned)n_images);
 	if (p2) {
-		if (g->interp == 0)      return launch(k_roll<1, true>, k_roll_p<1, true>);
-		else if (g->interp == 1) return launch(k_roll<2, true>, k_roll_p<2, true>);
-		else                     return launch(k_roll<4, true>, k_roll_p<4, true>);
+		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+		else                     hipLaunchKernelGGL((k_roll<4, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+	} else {
+		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+		else                     hipLaunchKernelGGL((k_roll<4, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
 	}
-	if (g->interp == 0)      return launch(k_roll<1, false>, k_roll_p<1, false>);
-	else if (g->interp == 1) return launch(k_roll<2, false>, k_roll_p<2, false>);
-	return launch(k_roll<4, false>, k_roll_p<4, false>);
+	return hipGetLastError();
 }
 
 extern "C" hipError_t

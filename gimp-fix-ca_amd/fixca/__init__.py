@@ -99,7 +99,7 @@ def _load():
         "fixca_preview_host": ([vp, vp, ci, ci, ci, ci, P, ci, ci, ci, ci], ci),
         "fixca_preview_device": ([vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp], ci),
         "fixca_noise_device": ([vp, ctypes.c_size_t, ctypes.c_ulonglong, vp], ci),
-        "fixca_debug_sched": ([ci, ci, ci, P, ci, ci, ctypes.POINTER(ci)], ci),
+        "fixca_debug_sched": ([ci, ci, ci, P, ci, ctypes.POINTER(ci)], ci),
         "fixca_debug_host_cache": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)], None),
         "fixca_last_error": ([], ctypes.c_char_p),
         "fixca_abi_version": ([], ci),
@@ -220,14 +220,13 @@ def noise_fill(t, seed):
     return t
 
 
-SCHED_FIELDS = ("ncols", "rows", "nbig", "big_blocks", "L", "Hb", "pool_chunks", "pool_waves", "pool_blocks", "th")
+SCHED_FIELDS = ("ncols", "rows", "pool_chunks", "pool_waves", "pool_blocks", "th")
 
 
-def debug_sched(orig_width, orig_height, bytes, params, n_images, resident):
-    """k_roll's tile schedule for a batch launch of n_images on a chip with `resident` wave slots
-    (0: unknown -> pool tiles only), as a dict; works without a GPU.  Test hook."""
-    out = (ctypes.c_int * 10)()
-    _check(lib.fixca_debug_sched(orig_width, orig_height, bytes, ctypes.byref(params), n_images, resident, out))
+def debug_sched(orig_width, orig_height, bytes, params, n_images):
+    """k_roll's tile schedule for a batch launch of n_images, as a dict; works without a GPU.  Test hook."""
+    out = (ctypes.c_int * 6)()
+    _check(lib.fixca_debug_sched(orig_width, orig_height, bytes, ctypes.byref(params), n_images, out))
     return dict(zip(SCHED_FIELDS, list(out)))
 
 

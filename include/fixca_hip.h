@@ -167,12 +167,11 @@ FIXCA_API const char *fixca_last_error(void);          /* thread-local, never NU
 FIXCA_API int         fixca_abi_version(void);         /* 1                            */
 
 /* ---- test hooks (used by tests/ only) ----------------------------------------------------
- * fixca_debug_sched: the tile schedule of a batch launch of the row-rolling kernel as 10 ints
- * {ncols, rows, nbig, big_blocks, L, Hb, pool_chunks, pool_waves, pool_blocks, th} for a chip with
- * `resident` wave slots (no GPU needed).  fixca_debug_host_cache: the calling thread's cached
- * device images of fixca_region_host. */
+ * fixca_debug_sched: the tile schedule of a batch launch of the row-rolling kernel as 6 ints
+ * {ncols, rows, pool_chunks, pool_waves, pool_blocks, th} (no GPU needed).  fixca_debug_host_cache: the
+ * calling thread's cached device images of fixca_region_host. */
 FIXCA_API int  fixca_debug_sched(int orig_width, int orig_height, int bytes, const FIXCA_PARAMS_T *params,
-                                 int n_images, int resident, int *out10);
+                                 int n_images, int *out6);
 FIXCA_API void fixca_debug_host_cache(void **src_image, void **dst_image, size_t *nbytes);
 
 #ifdef __cplusplus

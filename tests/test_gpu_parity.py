@@ -486,39 +486,13 @@ def test_batch_entry_replays_from_a_hip_graph(torch_cuda):
         assert mx <= TOL_LSB
 
 
-@pytest.mark.parametrize("channels", [4, 3])
-@pytest.mark.parametrize("interp", [0, 1, 2])
-def test_batch_two_level_schedule(torch_cuda, monkeypatch, channels, interp):
-    """big pieces + pool tiles (RollSched): pretend the chip holds 20 waves so that 8 small images are
-    scheduled the way 16+ full-size ones are: big pieces above, pool tiles below"""
-    torch = torch_cuda
-    monkeypatch.setenv("FIXCA_DEBUG_RESIDENT", "60")
-    w, h, n = 768, 400, 8
-    p = fixca.make_params(blue=0.9, red=-0.7, lens_x=300, lens_y=150, interpolation=interp, y_red=-0.5)
-    assert fixca.plan(w, h, channels, 1, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)[0] == 6
-    sc = fixca.debug_sched(w, h, channels, p, n, 60)
-    assert sc["nbig"] > 0 and sc["nbig"] % sc["ncols"] == 0 and sc["Hb"] > 0 and sc["pool_chunks"] > 0, sc
-    imgs = [synth.noise_image(900 + i, w, h, channels) for i in range(n)]
-    srcs = [torch.from_numpy(a).cuda() for a in imgs]
-    dsts = [torch.full_like(s, 0x55) for s in srcs]
-    fixca.fix_ca_batch(srcs, dsts, w, h, channels, 1, p)
-    torch.cuda.synchronize()
-    for a, d in zip(imgs, dsts):
-        out = d.cpu().numpy()
-        mx, cnt = diff_stats(out, oracle_run(a, p))
-        assert mx <= (0 if interp == 0 else TOL_LSB)
-        assert cnt <= 0.02 * out.size
-        assert np.array_equal(out[..., 1], a[..., 1])
-
-
 def test_batch_full_size_images_0_31_32_last(torch_cuda):
     """config 5's shape at reduced count: 40 images of 6000x4000 RGBA8 through the batch entry (one
-    launch of big pieces + pool tiles); images 0, 31, 32 and 39 against the fp64 kernel, which the
+    launch of 32 + one of 8); images 0, 31, 32 and 39 against the fp64 kernel, which the
     survey's md5 pins (test_full_size_configs)"""
     torch = torch_cuda
     w, h, n = 6000, 4000, 40
     p = fixca.make_params(blue=2.0, red=-2.0, lens_x=3000, lens_y=2000, interpolation=2)
-    sc = fixca.debug_sched(w, h, 4, p, n, 0)
     base = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda")
     srcs = [torch.roll(base, shifts=(7 * i, 13 * i), dims=(0, 1)) for i in range(n)]
     dsts = [torch.zeros_like(s) for s in srcs]
