@@ -307,6 +307,38 @@ def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
         assert np.all(got[:7] == 0x5A) and np.all(got[h - 3:] == 0x5A)
 
 
+@pytest.mark.parametrize("idx", range(24))
+def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
+    """random geometries and parameters (the 8-bit fuzz set) on the wide sample types: whatever kernel
+    the planner picks (k_wcol where the windows fit, the one-thread-per-pixel kernel otherwise, NONE
+    always) must reproduce the oracle bit for bit, full image or a row range"""
+    torch = torch_cuda
+    w, h, kw = _fuzz_cases(60, 0xF1CA)[idx]
+    bpc, dtype = WIDE[idx % 4]
+    nch = 3 if (idx // 4) % 2 else 4
+    sb = abs(bpc)
+    img = _wide_image(dtype, w, h, nch, 7000 + idx)
+    y1, y2 = (0, h) if idx % 3 else (h // 5, h - 2)
+    seen = set()
+    for interp in (0, 1, 2):
+        p = fixca.make_params(interpolation=interp, **kw)
+        try:
+            kid, desc = fixca.plan(w, h, nch * sb, bpc, p, y1=y1, y2=y2)
+        except fixca.FixCaError as e:
+            assert e.code == fixca.E_DOMAIN
+            continue
+        seen.add(kid)
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
+        src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+        dst = torch.full_like(src, 0x6B)
+        fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, y1, y2, True)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        assert got[y1:y2].tobytes() == ref.view(np.uint8).reshape(h, w, nch * sb)[y1:y2].tobytes(), (desc, kw)
+        assert np.all(got[:y1] == 0x6B) and np.all(got[y2:] == 0x6B)
+    assert seen <= {1, 7}
+
+
 @pytest.mark.parametrize("bpc,dtype", [(1, np.uint8)] + WIDE, ids=lambda v: str(v))
 @pytest.mark.parametrize("nch", [3, 4])
 @pytest.mark.parametrize("interp", [0, 2])
