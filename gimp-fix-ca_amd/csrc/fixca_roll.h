@@ -49,8 +49,11 @@ struct RollTables {
 };
 
 /* the images of one launch (independent, same geometry and parameters): a kernel argument */
-/* 32 images per launch measured best on 6000x4000 (16: 69.4 %, 32: 72.6 %, 64: 72.2 % of the HBM peak) */
-#define ROLL_BATCH_MAX 32
+/* images per launch, 6000x4000 cubic, 384 distinct images resident, one box (tools/r2_exp13.sh): 8: 70.1 %, 16: 69.4-71.4,
+ * 32: 71.1-71.6, 64: 71.8-71.9, 96: 72.1-72.2, 128: 68.7-72.2 % of the HBM peak */
+#ifndef ROLL_BATCH_MAX
+#define ROLL_BATCH_MAX 64
+#endif
 struct RollBatch {
 	const uint8_t *src[ROLL_BATCH_MAX];
 	uint8_t       *dst[ROLL_BATCH_MAX];

@@ -520,7 +520,7 @@ def test_batch_entry_replays_from_a_hip_graph(torch_cuda):
 
 def test_batch_full_size_images_0_31_32_last(torch_cuda):
     """config 5's shape at reduced count: 40 images of 6000x4000 RGBA8 through the batch entry (one
-    launch of 32 + one of 8); images 0, 31, 32 and 39 against the fp64 kernel, which the
+    launch); images 0, 31, 32 and 39 against the fp64 kernel, which the
     survey's md5 pins (test_full_size_configs)"""
     torch = torch_cuda
     w, h, n = 6000, 4000, 40
@@ -541,7 +541,7 @@ def test_batch_full_size_images_0_31_32_last(torch_cuda):
 
 
 def test_batch_entry_more_images_than_one_launch_takes(torch_cuda):
-    """the row-rolling kernel takes 32 images per launch: 70 images = 3 launches"""
+    """the row-rolling kernel takes 64 images per launch: 70 images = 2 launches"""
     torch = torch_cuda
     p = fixca.make_params(blue=0.5, red=-0.4, lens_x=300, lens_y=20, interpolation=2, x_blue=1.25, y_red=-0.5)
     assert fixca.plan(512, 40, 4, 1, p)[0] == 6
