@@ -229,7 +229,7 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
 #if defined(FIXCA_EXP_NOVMWAIT)                 /* timing experiment only: reads rows that may not have landed */
 	return;
 #endif
-	constexpr int LPR = 1 + ((ROLL_WIN > 256) ? 1 : 0);     /* loads per row */
+	constexpr int LPR = 1 + ((ROLL_BPP == 4 && ROLL_WIN > 256) ? 1 : 0);     /* loads per row (RGB8: one DMA whatever the window) */
 	const int younger = st.ld - need;
 	if (younger >= 8) roll_wait_vm<8 * LPR>();
 	else if (younger >= 6) roll_wait_vm<6 * LPR>();
