@@ -464,6 +464,9 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 {
 	if (g->interp == 0 || g->bpc == 1 || g->W < 2) return false;
 	if ((long long)g->W * g->H >= (1LL << 40)) return false;
+	/* the one case where the one-thread-per-pixel kernel measures faster: LINEAR on double samples (no get_pixel
+	 * division to save, 8 loads of 8 bytes per pixel: 396 vs 488 us for 6000x4000 RGBA) */
+	if (g->bpc == -8 && g->interp == 1) return false;
 	const int taps = (g->interp == 2) ? 4 : 2, back = (taps == 4) ? 1 : 0, W = g->W;
 	const int oc = WIDE_OC;
 	for (int c = 0; c < 2; ++c)
