@@ -221,6 +221,25 @@ extern "C" __attribute__((visibility("default"))) void fixca_debug_host_cache(vo
 	if (nbytes) *nbytes = g_cache.bytes;
 }
 
+/* the calling thread's two device images, at least `total` bytes each, on the current device */
+static int host_cache_reserve(size_t total)
+{
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (total > g_cache.bytes || dev != g_cache.device) {
+		for (int i = 0; i < 2; ++i) {
+			if (g_cache.buf[i]) (void)hipFree(g_cache.buf[i]);
+			g_cache.buf[i] = nullptr;
+		}
+		g_cache.bytes = 0;
+		g_cache.device = dev;
+		HIP_TRY(hipMalloc(&g_cache.buf[0], total));
+		HIP_TRY(hipMalloc(&g_cache.buf[1], total));
+		g_cache.bytes = total;
+	}
+	return FIXCA_OK;
+}
+
 /* rows above / below an output row that its taps can reach: |y' - y| <= |s - 1| * (distance of the
  * farthest row from the centre) + |shift|, plus the cubic window */
 static int vertical_reach(const FixcaGeom *g)
@@ -277,19 +296,8 @@ static int region_host_queue(const unsigned char *src, unsigned char *dst, int W
 {
 	int rc;
 	const size_t pitch = (size_t)W * bytes, total = pitch * H;
-	int dev = 0;
-	HIP_TRY(hipGetDevice(&dev));
-	if (total > g_cache.bytes || dev != g_cache.device) {
-		for (int i = 0; i < 2; ++i) {
-			if (g_cache.buf[i]) (void)hipFree(g_cache.buf[i]);
-			g_cache.buf[i] = nullptr;
-		}
-		g_cache.bytes = 0;
-		g_cache.device = dev;
-		HIP_TRY(hipMalloc(&g_cache.buf[0], total));
-		HIP_TRY(hipMalloc(&g_cache.buf[1], total));
-		g_cache.bytes = total;
-	}
+	rc = host_cache_reserve(total);
+	if (rc) return rc;
 	const char *ex = getenv("FIXCA_EXACT");
 	const unsigned flags = (ex && *ex && strcmp(ex, "0") != 0) ? FIXCA_KERNEL_EXACT : FIXCA_KERNEL_AUTO;
 	char *const d_src = static_cast<char *>(g_cache.buf[0]);
@@ -394,26 +402,15 @@ static int preview_host_queue(const unsigned char *src, unsigned char *prev, int
 	const size_t pitch = (size_t)W * bytes, total = pitch * H;
 	const int sb = bpc < 0 ? -bpc : bpc;
 	const size_t prev_bytes = (size_t)width * height * (bytes / sb);
-	int dev = 0;
-	HIP_TRY(hipGetDevice(&dev));
-	if (total > g_cache.bytes || dev != g_cache.device) {
-		for (int i = 0; i < 2; ++i) {
-			if (g_cache.buf[i]) (void)hipFree(g_cache.buf[i]);
-			g_cache.buf[i] = nullptr;
-		}
-		g_cache.bytes = 0;
-		g_cache.device = dev;
-		HIP_TRY(hipMalloc(&g_cache.buf[0], total));
-		HIP_TRY(hipMalloc(&g_cache.buf[1], total));
-		g_cache.bytes = total;
-	}
+	int rc = host_cache_reserve(total);
+	if (rc) return rc;
 	char *const d_src = static_cast<char *>(g_cache.buf[0]);
 	char *const d_dst = static_cast<char *>(g_cache.buf[1]);
 	const int reach = vertical_reach(&g);
 	const int lo = y - reach > 0 ? y - reach : 0;
 	const int hi = y + height + reach < H ? y + height + reach : H;
 	HIP_TRY(hipMemcpy(d_src + (size_t)lo * pitch, src + (size_t)lo * pitch, (size_t)(hi - lo) * pitch, hipMemcpyHostToDevice));
-	int rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, 0, W, y, y + height, 0, FIXCA_KERNEL_AUTO, NULL);
+	rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, 0, W, y, y + height, 0, FIXCA_KERNEL_AUTO, NULL);
 	if (rc) return rc;
 	/* the window is converted into the (already consumed) upload area: no third buffer */
 	void *d_prev = d_src;

@@ -639,10 +639,10 @@ template <typename S>
 __global__ __launch_bounds__(256) void
 k_preview(const S *__restrict__ img, uint8_t *__restrict__ prev, int W, int nch, int x, int y, int width, int height)
 {
-	const int n = width * nch;                      /* samples per window row */
+	const size_t n = (size_t)width * nch;           /* samples per window row */
 	const int i = blockIdx.y;
 	const S *row = img + ((size_t)W * (y + i) + x) * nch;
-	for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256)
+	for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256)
 		prev[(size_t)i * n + j] = u8_as_x86(round(__dmul_rn(SampleCodec<S>::get(row[j]), 255.0)));
 }
 
@@ -654,8 +654,9 @@ fixca_launch_preview(const void *d_img, void *d_prev, int W, int bytes, int bpc,
 	if (b == 1)                                      /* a plain crop (fix-ca.c:661-664) */
 		return hipMemcpy2DAsync(d_prev, (size_t)width * bytes, static_cast<const uint8_t *>(d_img) + ((size_t)W * y + x) * bytes,
 		                        (size_t)W * bytes, (size_t)width * bytes, height, hipMemcpyDeviceToDevice, stream);
-	const int n = width * nch;
-	const dim3 grid((n + 255) / 256 < 64 ? (n + 255) / 256 : 64, height), block(256);
+	const size_t n = (size_t)width * nch;
+	const dim3 grid((unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), (unsigned)(height < 65535 ? height : 65535)), block(256);
+	if (height > 65535) return hipErrorInvalidValue;         /* a preview window is a few hundred rows */
 	uint8_t *prev = static_cast<uint8_t *>(d_prev);
 	switch (bpc) {
 	case 2:  hipLaunchKernelGGL(k_preview<uint16_t>, grid, block, 0, stream, static_cast<const uint16_t *>(d_img), prev, W, nch, x, y, width, height); break;
