@@ -7,7 +7,7 @@ Workload (BASELINE.json): config 3's image and parameters (6000x4000 RGBA8, late
 red -2, lens (658,1280), cubic) as config 5's batch: G = 512 independent images, image i =
 noise(0xF1CA1000 + i) generated on the device, image i owned by rank i mod N.
 One step = one pass of the hot path over the rank's images: fixca_batch_device -> the row-rolling
-kernel, 64 images per launch.  Nothing is re-used between launches (98 GB of pixels at N = 1), so
+kernel, 128 images per launch.  Nothing is re-used between launches (98 GB of pixels at N = 1), so
 no cache level can serve a repeat.  N > 1 (one rank per GPU, torch.distributed.run): rank 0
 broadcasts the 80-byte parameter block over RCCL, no pixel crosses GPUs, the total work is fixed
 (strong scaling).  Prints ONE JSON line on rank 0.
@@ -130,7 +130,7 @@ def run_configs(torch, fixca, dev, per_launch):
     for cfg in CONFIGS:
         w, h, c, bpc = cfg["w"], cfg["h"], cfg["c"], cfg["bpc"]
         bytes_pp = c * sample_bytes(bpc)
-        n = cfg.get("images", per_launch)
+        n = cfg.get("images", min(per_launch, 64 if cfg["w"] * cfg["h"] <= 6000 * 4000 else 32))
         p = fixca.make_params(**cfg["params"])
         entry = {"name": cfg["name"], "width": w, "height": h, "bytes_per_pixel": bytes_pp, "bpc": bpc}
         try:
@@ -204,10 +204,10 @@ def cold_call(torch, hsrc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--global-batch", type=int, default=512, help="images of the whole job (BASELINE config 5: 512)")
-    ap.add_argument("--per-launch", type=int, default=64, help="images per kernel launch (the library takes up to 64)")
+    ap.add_argument("--per-launch", type=int, default=128, help="images per kernel launch (the library takes up to 128)")
     ap.add_argument("--batch", type=int, default=0, help="shorthand: global batch = this many images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -250,7 +250,7 @@ def main():
     G = args.batch * world if args.batch else args.global_batch
     own = fdist.shard_indices(G, rank, world)               # image i -> rank i mod N
     n_own = len(own)
-    P = max(1, min(args.per_launch, 64))
+    P = max(1, min(args.per_launch, 128))
     src_all = torch.empty((n_own, H, W, C), dtype=torch.uint8, device=dev)
     dst_all = torch.empty_like(src_all)
     for j, i in enumerate(own):

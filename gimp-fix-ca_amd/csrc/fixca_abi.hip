@@ -23,7 +23,7 @@ extern "C" hipError_t fixca_launch_centerline(void *, const FixcaGeom *, hipStre
 extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch_rgb(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
-/* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (64) per launch, the
+/* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (128) per launch, the
  * other kernels one */
 static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
                        hipStream_t stream, int *launches);

@@ -341,7 +341,7 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	/* Strip width: a multiple of 16 pixels makes every row store start and end on a 64-byte
 	 * boundary (no memory line is shared by two waves' stores; measured 6 % faster than the
 	 * widest width that fits, 248); other widths only if no such width fits. */
-	const int oc_top = (ROLL_WIN > 256) ? 256 : 252;
+	const int oc_top = ROLL_NEXT_FROM_LDS ? 256 : 252;
 	const int oc_env = env_int("FIXCA_OC", 0, 0, oc_top) & ~3;
 	/* the width search walks every column for every candidate width and does not depend on the
 	 * row range: remembered per thread, so that a caller working through an image in row bands

@@ -24,6 +24,14 @@
 #define ROLL_U0_MASK 3
 #endif
 
+/* With a window wider than 256 columns the pixels after a lane's own 4 can be read from LDS by the
+ * lane itself (ROLL_NEXT_FROM_LDS 1: strips of 256 columns, every lane produces) or still come from
+ * lane L + 1 over DPP (0: strips up to 252 columns; the extra columns only let the window START on a
+ * 64-byte boundary: -DROLL_WIN=272 -DROLL_U0_MASK=15 -DROLL_NEXT_FROM_LDS=0). */
+#ifndef ROLL_NEXT_FROM_LDS
+#define ROLL_NEXT_FROM_LDS (ROLL_WIN > 256)
+#endif
+
 /* one strip of `oc` output columns (16 bytes) */
 struct RollStrip {
 	int U0;             /* first column of the 256-column source window (multiple of 4)          */
@@ -49,10 +57,11 @@ struct RollTables {
 };
 
 /* the images of one launch (independent, same geometry and parameters): a kernel argument */
-/* images per launch, 6000x4000 cubic, 384 distinct images resident, one box (tools/r2_exp13.sh): 8: 70.1 %, 16: 69.4-71.4,
- * 32: 71.1-71.6, 64: 71.8-71.9, 96: 72.1-72.2, 128: 68.7-72.2 % of the HBM peak */
+/* Images per launch.  6000x4000 cubic on ONE allocation of 128 images (tools/ab.py; the spread between rounds is
+ * 0.1 point): 16 per launch 71.1 %, 32: 71.4, 64: 71.8, 128: 72.1 % of the HBM peak.  128 x 16 bytes of pointers
+ * is 2 KiB of the 4 KiB a kernel's arguments may take. */
 #ifndef ROLL_BATCH_MAX
-#define ROLL_BATCH_MAX 64
+#define ROLL_BATCH_MAX 128
 #endif
 struct RollBatch {
 	const uint8_t *src[ROLL_BATCH_MAX];

@@ -298,7 +298,7 @@ __device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, const
 		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
 #pragma unroll
 	for (int k = 4; k < NP; ++k)
-#if ROLL_WIN > 256
+#if ROLL_NEXT_FROM_LDS
 		tp[k] = f32x2{ (float)(nr[k - 4] & 0xffu), (float)((nb[k - 4] >> 16) & 0xffu) };
 #else
 		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
@@ -309,7 +309,7 @@ __device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, const
 	tp[1] = f32x2{ ubyte_f32(pr[0], 3), ubyte_f32(pb[1], 1) };
 	tp[2] = f32x2{ ubyte_f32(pr[1], 2), ubyte_f32(pb[2], 0) };
 	tp[3] = f32x2{ ubyte_f32(pr[2], 1), ubyte_f32(pb[2], 3) };
-#if ROLL_WIN > 256
+#if ROLL_NEXT_FROM_LDS
 	const uint32_t nr0 = nr[0], nr1 = nr[1], nr2 = nr[2], nb0 = nb[0], nb1 = nb[1], nb2 = nb[2];
 #else
 	const uint32_t nr0 = next_lane_dword(pr[0]), nr1 = next_lane_dword(pr[1]), nr2 = next_lane_dword(pr[2]);
@@ -326,7 +326,7 @@ __device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, const
 template <int TAPS, bool P2>
 __device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2> &st, int row, int off)
 {
-#if ROLL_WIN > 256
+#if ROLL_NEXT_FROM_LDS
 	return roll_ring_win(st, row, off + 4 * ROLL_BPP);
 #else
 	return u32x4{ 0u, 0u, 0u, 0u };
@@ -590,7 +590,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	}
 	/* lanes past the last producing lane only serve as its DPP neighbour: they all read where
 	 * lane `nact` reads, so a narrow last strip never reads far outside its ring row */
-	constexpr int NB = (ROLL_WIN > 256) ? 1 : 0;     /* 256-column window: lane nact serves as lane nact-1's DPP neighbour */
+	constexpr int NB = ROLL_NEXT_FROM_LDS ? 1 : 0;     /* 256-column window: lane nact serves as lane nact-1's DPP neighbour */
 	st.tap[0] = (hd.tapR + 4 * min(lane, nact - NB)) * ROLL_BPP;
 	st.tap[1] = (hd.tapB + 4 * min(lane, nact - NB)) * ROLL_BPP;
 	st.my_idt = (uint32_t)((X0 - U0) + 4 * min(lane, nact - 1)) * ROLL_BPP;

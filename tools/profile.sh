@@ -1,10 +1,10 @@
 #!/bin/bash
 # Profiles bench.py's timed region on the GPU box (run through gpurun from the repo root):
 #   tools/profile.sh <tag>
-# pass 1: rocprofv3 --kernel-trace --stats over the default workload (512 images, 64 per launch):
-#         (2 warmup + 8 timed steps) x 8 launches = 80 launches of k_roll -> per-kernel durations
+# pass 1: rocprofv3 --kernel-trace --stats over the default workload (512 images, 128 per launch):
+#         (4 warmup + 16 timed steps) x 4 launches = 80 launches of k_roll -> per-kernel durations
 # pass 2..: rocprofv3 --pmc <counters>, one set per pass (never combined with tracing), on 128 images
-#         (2 launches per step, the same 64 images per launch: the counters are per launch)
+#         (1 launch per step, the same 128 images per launch: the counters are per launch)
 # Everything lands under gpurun_out/prof_<tag>/ ; copy the summaries worth keeping to profiles/.
 set -e
 TAG=${1:-r02}
@@ -12,8 +12,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras"
-export FIXCA_PROF_IMAGES=64      # images per k_roll launch in that command
+CMD="python3 $ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-extras"
+export FIXCA_PROF_IMAGES=128      # images per k_roll launch in that command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --global-batch 128"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
