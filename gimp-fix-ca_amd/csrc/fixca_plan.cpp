@@ -463,7 +463,8 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
 static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 {
 	if (g->interp == 0 || g->bpc == 1 || g->W < 2) return false;
-	if ((long long)g->W * g->H >= (1LL << 40)) return false;
+	/* the kernel addresses the image through 32-bit buffer offsets: rows below 8 MB, image below 4 GB */
+	if ((long long)g->W * g->bpp >= (8LL << 20) || (long long)g->W * g->bpp * g->H >= (1LL << 32) - 4096) return false;
 	/* the one case where the one-thread-per-pixel kernel measures faster: LINEAR on double samples (no get_pixel
 	 * division to save, 8 loads of 8 bytes per pixel: 396 vs 488 us for 6000x4000 RGBA) */
 	if (g->bpc == -8 && g->interp == 1) return false;
@@ -471,15 +472,36 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 	const int oc = WIDE_OC;
 	for (int c = 0; c < 2; ++c)
 		for (int X0 = 0; X0 < W; X0 += oc) {
+			/* window origin as the kernel takes it: the strip's lowest tap, unclamped (-1 at the left edge), rounded
+			 * down to even; the clamped taps of the reference are then consecutive window slots (fixca_wide.hip) */
 			const int xl = (X0 + oc < W ? X0 + oc : W) - 1;
-			const int f = clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1) & ~1;
-			const int l = clampi((int)floor(h_map_dbl(xl, g->xc, W, g->s[c], g->xs[c])) - back + taps - 1, 0, W - 1);
+			const int f = ((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back) & ~1;
+			const int l = (int)floor(h_map_dbl(xl, g->xc, W, g->s[c], g->xs[c])) - back + taps - 1;
 			if (l - f > WIDE_WIN - 1) return false;
 			/* the map is monotone for s > 0, so no column of the strip reaches below f or above l */
 		}
 	pl->kernel = FIXCA_K_WCOL;
 	pl->oc = oc;
-	pl->th = env_int("FIXCA_TH", 64, 1, WIDE_TH_MAX);
+	/* Tile height: all tiles resident at once, the same number on every SIMD.  The kernel is bound by fp64 issue and its
+	 * waves all do the same work, so a launch lasts as long as its fullest SIMD (6000x4000 RGBA u16, 3 resident waves
+	 * per SIMD: th 66 -> 3050 waves 132 us; th 60 -> 3350 waves 164 us; th 90 -> 2250 waves 170 us).  Several rounds
+	 * when one would need tiles above WIDE_TH_MAX.  Tried and dropped: resident waves taking small tiles from an
+	 * atomic queue (evens out the SIMDs, but a tile's start costs as much as 19 rows: 184-250 us). */
+	{
+		const int q = WIDE_SLOTS * (WIDE_SLOTS - 1), th_max = WIDE_TH_MAX / q * q, rows = g->y2 - g->y1, nstrips = (W + oc - 1) / oc;
+		int slots = fixca_wide_slots(g);
+		if (slots <= 0) slots = 12 * 256;                  /* no device to ask (planning on a CPU-only machine) */
+		const int per_round = slots / nstrips > 0 ? slots / nstrips : 1;
+		int th = (rows + per_round - 1) / per_round;
+		if (th > th_max) {
+			const int rounds = (th + th_max - 1) / th_max;
+			th = (rows + per_round * rounds - 1) / (per_round * rounds);
+		}
+		th = (th + q - 1) / q * q;
+		if (th < 2 * q) th = 2 * q;
+		if (th > th_max) th = th_max;
+		pl->th = env_int("FIXCA_TH", th, 1, WIDE_TH_MAX);
+	}
 	pl->nstrips = (W + oc - 1) / oc;
 	pl->nchunks = (g->y2 - g->y1 + pl->th - 1) / pl->th;
 	if (pl->nchunks < 1) pl->nchunks = 1;

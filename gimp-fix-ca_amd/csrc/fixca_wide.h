@@ -6,6 +6,14 @@
 #define WIDE_TH_MAX 128 /* most output rows per tile (per-row tables in LDS)                  */
 #define WIDE_WIN  128   /* source columns per channel window: 64 lanes x 2                   */
 
+#ifndef WIDE_SLOTS
+#define WIDE_SLOTS 3   /* register queue of row loads: WIDE_SLOTS - 1 rows in flight ahead of the row being computed */
+#endif
+
+struct FixcaGeom;
+/* waves of the geometry's k_wcol instantiation the device holds at once, 0 if there is no device to ask (fixca_wide.hip) */
+extern "C" int fixca_wide_slots(const struct FixcaGeom *g);
+
 struct WidePlan {
 	int oc, th, nstrips, nwaves, nblocks;
 };

@@ -27,6 +27,7 @@
  */
 #include "fixca_device.h"
 #include "fixca_wide.h"
+#include <mutex>
 
 namespace {
 
@@ -41,67 +42,118 @@ __device__ __forceinline__ double div_exact(double x, double d, double r)
 }
 /* C round() (half away from zero, set_pixel fix-ca.c:752-761) of a value in [0, 2^32): the integer part plus one if
  * the (exactly computed) fraction is at least one half.  Not floor(x + 0.5): that rounds 0.49999999999999994 up. */
-__device__ __forceinline__ double round_nonneg(double x)
+__device__ __forceinline__ uint32_t round_nonneg(double x)
 {
-	const double t = trunc(x);
-	return (__dsub_rn(x, t) >= 0.5) ? __dadd_rn(t, 1.0) : t;
+	/* v_fract_f64 is x - floor(x), exact for these magnitudes; the conversion truncates */
+	return (uint32_t)x + (__builtin_amdgcn_fract(x) >= 0.5 ? 1u : 0u);
 }
 template <> struct Codec<uint16_t> {
 	static __device__ __forceinline__ double get(uint16_t s) { return div_exact((double)s, 65535.0, 1.0 / 65535.0); }
-	static __device__ __forceinline__ uint16_t put(double d) { return (uint16_t)(unsigned)round_nonneg(__dmul_rn(d, 65535.0)); }
+	static __device__ __forceinline__ uint16_t put(double d) { return (uint16_t)round_nonneg(__dmul_rn(d, 65535.0)); }
+	static constexpr bool INTEGER = true;
 };
 template <> struct Codec<uint32_t> {
 	static __device__ __forceinline__ double get(uint32_t s) { return div_exact((double)s, 4294967295.0, 1.0 / 4294967295.0); }
-	static __device__ __forceinline__ uint32_t put(double d) { return (uint32_t)round_nonneg(__dmul_rn(d, 4294967295.0)); }
+	static __device__ __forceinline__ uint32_t put(double d) { return round_nonneg(__dmul_rn(d, 4294967295.0)); }
+	static constexpr bool INTEGER = true;
 };
 template <> struct Codec<float> {
 	static __device__ __forceinline__ double get(float s) { return (double)s; }
 	static __device__ __forceinline__ float put(double d) { return (float)d; }
+	static constexpr bool INTEGER = false;
 };
 template <> struct Codec<double> {
 	static __device__ __forceinline__ double get(double s) { return s; }
 	static __device__ __forceinline__ double put(double d) { return d; }
+	static constexpr bool INTEGER = false;
 };
 
-/* two pixels of NCH samples, as stored: loaded and stored as one unit (16 bytes for RGBA u16) */
-/* guaranteed alignment of an even pixel's address: 4 samples per pixel -> a multiple of 4 * sizeof(S) (at most 16 is of
- * use); 3 samples per pixel -> only that of a sample */
-template <typename S, int NCH> struct __attribute__((packed, aligned(NCH == 4 ? (4 * sizeof(S) < 16 ? 4 * sizeof(S) : 16) : sizeof(S)))) Px2 { S v[2 * NCH]; };
-
-/* My two pixels are 2 * NCH * sizeof(S) contiguous bytes.  They are moved as 16-byte pieces whenever the address is a
- * multiple of 16 (RGBA: always for even image widths, every other row for odd ones): a wave's store instruction then
- * writes whole 64-byte sectors.  With the 8-byte pieces the type's guaranteed alignment allows, every sector is written
- * twice, half each time, and the write traffic to HBM doubles (measured: WRITE_SIZE 433 MB for a 192 MB image). */
+/* ---- pixel moves -------------------------------------------------------------------------------
+ * Pixels travel as dwords through raw buffer loads / stores (descriptor = the image for loads, the
+ * tile's own rows for stores, so a lane that must not write is given an offset past the range and
+ * the instruction stays unconditional: the loop body has no branch around a memory instruction and
+ * the compiler can count its waits exactly).  A run of N dwords moves as 16/12/8/4-byte pieces:
+ * buffer instructions need dword alignment only, which every pixel has when a pixel is a multiple
+ * of 4 bytes or the width is even; RGB u16 rows of odd width move as halfwords. */
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-template <typename S, int NCH>
-__device__ __forceinline__ void load_px2(const S *p, Px2<S, NCH> &out)
+
+template <int N>
+__device__ __forceinline__ void load_dwords(rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t *w)
 {
-	constexpr int BYTES = 2 * NCH * (int)sizeof(S);
-	if constexpr (BYTES % 16 == 0) {
-		if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-			const u32x4_t *q = reinterpret_cast<const u32x4_t *>(p);
-			u32x4_t *o = reinterpret_cast<u32x4_t *>(&out);
-#pragma unroll
-			for (int i = 0; i < BYTES / 16; ++i) o[i] = q[i];
-			return;
-		}
+	if constexpr (N >= 4) {
+		const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+		w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+		load_dwords<N - 4>(rs, voff + 16, soff, w + 4);
+	} else if constexpr (N == 3) {
+		const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 0);
+		w[0] = v.x; w[1] = v.y; w[2] = v.z;
+	} else if constexpr (N == 2) {
+		const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+		w[0] = v.x; w[1] = v.y;
+	} else if constexpr (N == 1) {
+		w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
 	}
-	out = *reinterpret_cast<const Px2<S, NCH> *>(p);
 }
-template <typename S, int NCH>
-__device__ __forceinline__ void store_px2(S *p, const Px2<S, NCH> &in)
+template <int N>
+__device__ __forceinline__ void store_dwords(rsrc_t rd, uint32_t voff, uint32_t soff, const uint32_t *w)
 {
-	constexpr int BYTES = 2 * NCH * (int)sizeof(S);
-	if constexpr (BYTES % 16 == 0) {
-		if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-			u32x4_t *q = reinterpret_cast<u32x4_t *>(p);
-			const u32x4_t *o = reinterpret_cast<const u32x4_t *>(&in);
-#pragma unroll
-			for (int i = 0; i < BYTES / 16; ++i) __builtin_nontemporal_store(o[i], &q[i]);
-			return;
-		}
+	if constexpr (N >= 4) {
+		__builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ w[0], w[1], w[2], w[3] }, rd, voff, soff, 2);
+		store_dwords<N - 4>(rd, voff + 16, soff, w + 4);
+	} else if constexpr (N == 3) {
+		__builtin_amdgcn_raw_buffer_store_b96(u32x3_t{ w[0], w[1], w[2] }, rd, voff, soff, 2);
+	} else if constexpr (N == 2) {
+		__builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ w[0], w[1] }, rd, voff, soff, 2);
+	} else if constexpr (N == 1) {
+		__builtin_amdgcn_raw_buffer_store_b32(w[0], rd, voff, soff, 2);
 	}
-	*reinterpret_cast<Px2<S, NCH> *>(p) = in;
+}
+/* NH halfwords <-> the low/high halves of consecutive dwords, from halfword `first` on */
+template <int NH>
+__device__ __forceinline__ void load_halves(rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t *w)
+{
+#pragma unroll
+	for (int i = 0; i < (NH + 1) / 2; ++i) w[i] = 0;
+#pragma unroll
+	for (int i = 0; i < NH; ++i)
+		w[i / 2] |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff + 2 * i, soff, 0) << (16 * (i & 1));
+}
+template <int NH>
+__device__ __forceinline__ void store_halves(rsrc_t rd, uint32_t voff, uint32_t soff, const uint32_t *w, int first)
+{
+#pragma unroll
+	for (int i = 0; i < NH; ++i) {
+		const int k = first + i;
+		__builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w[k / 2] >> (16 * (k & 1))), rd, voff + 2 * i, soff, 2);
+	}
+}
+
+/* sample k of a run of pixels held as dwords */
+template <typename S>
+__device__ __forceinline__ S get_sample(const uint32_t *w, int k)
+{
+	if constexpr (sizeof(S) == 2) return (S)(w[k / 2] >> (16 * (k & 1)));
+	else if constexpr (sizeof(S) == 4) return __builtin_bit_cast(S, w[k]);
+	else return __builtin_bit_cast(S, (unsigned long long)w[2 * k] | ((unsigned long long)w[2 * k + 1] << 32));
+}
+template <typename S>
+__device__ __forceinline__ void set_sample(uint32_t *w, int k, S v)
+{
+	if constexpr (sizeof(S) == 2) w[k / 2] = (k & 1) ? ((w[k / 2] & 0x0000FFFFu) | ((uint32_t)v << 16)) : ((w[k / 2] & 0xFFFF0000u) | (uint32_t)v);
+	else if constexpr (sizeof(S) == 4) w[k] = __builtin_bit_cast(uint32_t, v);
+	else { const unsigned long long b = __builtin_bit_cast(unsigned long long, v); w[2 * k] = (uint32_t)b; w[2 * k + 1] = (uint32_t)(b >> 32); }
+}
+
+/* clip_d (fix-ca.c:873-880) ahead of set_pixel.  For the integer sample types the two compares and selects are a max
+ * and a min: the operand is finite, and the sign of a zero does not survive the conversion. */
+template <bool INTEGER>
+__device__ __forceinline__ double clip_for_put(double d)
+{
+	if constexpr (INTEGER) return __builtin_fmin(__builtin_fmax(d, 0.0), 1.0);
+	else return clip01(d);
 }
 
 template <int TAPS>
@@ -128,203 +180,368 @@ __device__ __forceinline__ int tap_index(int c0, int t, int n)
 	return max(0, min(c0 - BACK + t, n - 1));
 }
 
-template <typename S, int NCH, int TAPS>
-__global__ __launch_bounds__(64) void
+
+/*
+ * Q = slots of the register queue of loads; Q - 1 rows of loads are in flight ahead of the row being
+ * computed.  Every output row needs, per channel, the one source row its sliding window gains (row
+ * tap_index(y0, T-1)) and its own pixels (green and alpha): those 3 loads are issued Q - 1 rows early,
+ * always (when the window does not move the row is fetched anyway and not used), so the steady-state
+ * body is straight-line code.  Row r uses slot r mod Q in place and the slot is refilled when row
+ * r + 1 starts: with the loop unrolled Q times every slot keeps its registers across the back edge
+ * (a slot refilled while its old value is still in use would need a copy there, and a copy of a
+ * register with a load in flight is a full s_waitcnt).
+ */
+#ifdef WIDE_WAVES_PER_EU
+#define WIDE_OCC __attribute__((amdgpu_waves_per_eu(WIDE_WAVES_PER_EU)))
+#else
+#define WIDE_OCC
+#endif
+template <typename S, int NCH, int TAPS, int Q, bool ODDW>
+__global__ __launch_bounds__(64) WIDE_OCC void
 k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 {
 	typedef Codec<S> C;
-	typedef Px2<S, NCH> P2;
-	constexpr int T = TAPS;
-	__shared__ double hbuf[2][128];                       /* one source row's converted samples per channel */
-	__shared__ double row_fy[2][WIDE_TH_MAX + 1];         /* per output row of the tile (and one past it): fraction ... */
-	__shared__ int    row_y0[2][WIDE_TH_MAX + 1];         /* ... and floor of the source coordinate               */
+	constexpr int T = TAPS, BACK = (T == 4) ? 1 : 0;
+	constexpr int SB = (int)sizeof(S);
+	constexpr int PB = NCH * SB;                          /* bytes per pixel                       */
+	constexpr int NW = 2 * PB / 4;                        /* dwords per pixel pair                 */
+	constexpr bool PAIRWIN = SB == 2;                     /* window rows fetched as whole pixel pairs (16 or 12 bytes a lane) */
+	constexpr int RW = PAIRWIN ? NW : 2 * SB / 4;         /* dwords of one window fetch            */
+	constexpr bool ALIGNED = PB % 4 == 0;                 /* every pixel starts on a dword         */
+	__shared__ double hbuf[2][WIDE_WIN];                  /* one source row's converted samples per channel */
+	__shared__ double row_fy[2][WIDE_TH_MAX];             /* per output row of the tile: fraction ...       */
+	__shared__ int    row_y0[2][WIDE_TH_MAX];             /* ... and floor of the source coordinate          */
 
 	const int lane = threadIdx.x;
+	const int W = g.W, H = g.H;
 	const int tile = xcd_remap(blockIdx.x, wp.nblocks);
 	if (tile >= wp.nwaves) return;
 	const int strip = tile % wp.nstrips, chunk = tile / wp.nstrips;
-	const int W = g.W, H = g.H;
 	const int X0 = strip * wp.oc;
 	const int Y0 = g.y1 + chunk * wp.th;
 	const int nrows = min(wp.th, g.y2 - Y0);
-	const size_t pitch = (size_t)W * NCH;                /* in samples */
-	const int xe = min(X0 + wp.oc, W);                   /* one past my strip's last output column */
-	const int x = X0 + 2 * lane;                         /* my two output columns: x, x + 1 */
+	const uint32_t pitchB = (uint32_t)W * PB;             /* the planner keeps the image below 4 GB */
+	const int xe = min(X0 + wp.oc, W);                    /* one past my strip's last output column */
+	const int x = X0 + 2 * lane;                          /* my two output columns: x, x + 1 */
 	const bool act0 = x < xe, act1 = x + 1 < xe;
+	constexpr bool al4 = ALIGNED || !ODDW;                /* pixel pairs start on a dword (ODDW: the width is odd) */
 
-	/* ---- per-lane column constants: tap slots in the channel's window, fractions --------------- */
-	int    U[2];                                          /* window start per channel (even)          */
-	int    slot[2][2][T];                                 /* [channel][pixel][tap] -> index in hbuf    */
-	double fx[2][2];
+	const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<S *>(src), 0, (uint32_t)H * pitchB, 0x00020000);
+	const uint32_t dst_range = (uint32_t)nrows * pitchB;  /* also the offset that makes a lane's store a no-op */
+	const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(dst) + (size_t)Y0 * pitchB, 0, dst_range, 0x00020000);
+
+	/* ---- per-lane column constants ------------------------------------------------------------
+	 * Channel c's window is source columns Uw .. Uw + 127, clamped into the image when they are FETCHED
+	 * (hbuf[i] = sample at clamp(Uw + i, 0, W - 1)): the reference's clamped taps
+	 * clamp(c0 - BACK + t, 0, W - 1) are then hbuf[c0 - BACK - Uw + t] with no clamp, 4 consecutive doubles. */
+	typedef const __attribute__((address_space(3))) double *lds_dp;
+	lds_dp   hb[2][2];                                    /* tap 0 in hbuf, per channel and pixel */
+	uint32_t wcol[2][2];                                  /* byte offset in a row of the sample (or pair) this lane fetches */
+	int      sel[2][2];                                   /* PAIRWIN: which pixel of the fetched pair is window column 2 * lane + j */
+	double   fx[2][2];
 #pragma unroll
 	for (int c = 0; c < 2; ++c) {
 		const double xd0 = map_dbl(X0, g.xc, W, g.s[c], g.xs[c]);
-		U[c] = tap_index<T>((int)floor(xd0), 0, W) & ~1;    /* the strip's first column has the lowest tap (the map is monotone) */
-		U[c] = __builtin_amdgcn_readfirstlane(U[c]);
+		const int Uw = __builtin_amdgcn_readfirstlane(((int)floor(xd0) - BACK) & ~1);   /* the strip's first column has the lowest tap (the map is monotone); may be -2 */
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			const int xx = min(x + j, W - 1);
 			const double xd = map_dbl(xx, g.xc, W, g.s[c], g.xs[c]);
 			const int c0 = (int)floor(xd);
 			fx[c][j] = __dsub_rn(xd, (double)c0);
-#pragma unroll
-			for (int t = 0; t < T; ++t) slot[c][j][t] = min(tap_index<T>(c0, t, W) - U[c], 127);
+			const int b = max(0, min(c0 - BACK - Uw, WIDE_WIN - T));              /* the planner guarantees the range */
+			hb[c][j] = (lds_dp)&hbuf[c][0] + b;
+		}
+		const int col0 = max(0, min(Uw + 2 * lane, W - 1)), col1 = max(0, min(Uw + 2 * lane + 1, W - 1));
+		if constexpr (PAIRWIN && al4) {
+			const int bp = max(0, min(Uw + 2 * lane, W - 2));
+			wcol[c][0] = wcol[c][1] = (uint32_t)bp * PB;
+			sel[c][0] = col0 - bp; sel[c][1] = col1 - bp;
+		} else {
+			wcol[c][0] = (uint32_t)col0 * PB + 2 * c * SB;
+			wcol[c][1] = (uint32_t)col1 * PB + 2 * c * SB;
+			sel[c][0] = sel[c][1] = 0;
 		}
 	}
-
-	/* the horizontally filtered window rows of my two columns, per channel */
-	double hh[2][2][T];
-	int    y0prev[2] = { -1000000, -1000000 };
-
-	/* the raw samples of my two window columns of source row r, channel c (loads only: no wait here) */
-	auto fetch = [&](int c, int r, S (&raw)[2]) {
-		const S *row = src + (size_t)r * pitch + 2 * c;
-#pragma unroll
-		for (int j = 0; j < 2; ++j) raw[j] = row[(size_t)min(U[c] + 2 * lane + j, W - 1) * NCH];
+	struct Raw { uint32_t w[RW]; };
+	/* the window columns of this lane in source row r, channel c (loads only: nothing waits here) */
+	auto fetch = [&](int c, int r, Raw &raw) {
+		const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)r * pitchB);
+		if constexpr (PAIRWIN) {
+			if constexpr (al4) load_dwords<NW>(rs, wcol[c][0], so, raw.w);
+			else {
+				raw.w[0] = __builtin_amdgcn_raw_buffer_load_b16(rs, wcol[c][0], so, 0);
+				raw.w[1] = __builtin_amdgcn_raw_buffer_load_b16(rs, wcol[c][1], so, 0);
+			}
+		} else {
+			load_dwords<SB / 4>(rs, wcol[c][0], so, raw.w);
+			load_dwords<SB / 4>(rs, wcol[c][1], so, raw.w + SB / 4);
+		}
 	};
-	/* get_pixel on them, shared with the wave through LDS, then the horizontal filter of my two columns */
-	auto absorb = [&](int c, const S (&raw)[2], double (&out)[2]) {
+	/* get_pixel on them, left in LDS for the wave (hbuf[c][i] = window column i of the row) */
+	auto convert = [&](int c, const Raw &raw) {
+		S s[2];
+		if constexpr (PAIRWIN) {
+			if constexpr (al4) {
+				const S p0 = get_sample<S>(raw.w, 2 * c), p1 = get_sample<S>(raw.w, NCH + 2 * c);
+				s[0] = sel[c][0] ? p1 : p0; s[1] = sel[c][1] ? p1 : p0;
+				/* every dword the load writes stays allocated until here: the compiler would otherwise hand the ones this
+				 * channel does not read to other values while the load is in flight, and wait for the load to do so */
 #pragma unroll
-		for (int j = 0; j < 2; ++j) hbuf[c][2 * lane + j] = C::get(raw[j]);
-		/* one wave: LDS operations of a wave complete in order, the reads below see the writes above */
+				for (int i = 0; i < RW; ++i) asm volatile("" :: "v"(raw.w[i]));
+			} else { s[0] = (S)raw.w[0]; s[1] = (S)raw.w[1]; }
+		} else { s[0] = get_sample<S>(raw.w, 0); s[1] = get_sample<S>(raw.w, 1); }
+		hbuf[c][2 * lane] = C::get(s[0]);
+		hbuf[c][2 * lane + 1] = C::get(s[1]);
+	};
+	/* the horizontal filter of my two columns on the row in hbuf[c].  One wave: its LDS operations complete in order,
+	 * the reads see the writes of convert() */
+	auto hrow = [&](int c, double (&out)[2]) {
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			double p[T];
 #pragma unroll
-			for (int t = 0; t < T; ++t) p[t] = hbuf[c][slot[c][j][t]];
+			for (int t = 0; t < T; ++t) p[t] = hb[c][j][t];
 			out[j] = hfilter<T>(p, fx[c][j]);
 		}
 	};
 	/* The row coordinates are the same for every lane: lane L computes those of row Y0 + L (and
 	 * Y0 + 64 + L) once per tile instead of every lane computing all of them every row. */
-	for (int i = lane; i <= nrows; i += 64) {
+	for (int i = lane; i < nrows; i += 64) {
 #pragma unroll
 		for (int c = 0; c < 2; ++c) {
-			const double yd = map_dbl(min(Y0 + i, H - 1), g.yc, H, g.s[c], g.ys[c]);
+			const double yd = map_dbl(Y0 + i, g.yc, H, g.s[c], g.ys[c]);
 			const int y0 = (int)floor(yd);
 			row_y0[c][i] = y0;
 			row_fy[c][i] = __dsub_rn(yd, (double)y0);
 		}
 	}
 
-	/* Software pipeline: while row y is computed, the loads of row y + 1 (the one new source row per
-	 * channel of a sliding window, and the pixels to copy green/alpha from) are already in flight. */
-	S   pend[2][2];                                       /* prefetched raw samples per channel      */
-	int pend_row[2] = { -1, -1 };                         /* the source row they belong to           */
-	P2  idt;                                              /* my two pixels of the current output row */
-	const size_t xoff = (size_t)min(x, W - 2) * NCH;      /* W >= 2 is guaranteed by the planner      */
-	load_px2<S, NCH>(src + (size_t)Y0 * pitch + xoff, idt);
-
-	for (int r = 0; r < nrows; ++r) {
-		const int y = Y0 + r;
-		int    y0[2];
-		double fy[2];
-		S      cur[2][2];
-		int    cur_row[2];
+	/* ---- the queue of loads in flight ----------------------------------------------------------
+	 * A slot holds everything output row r needs from memory and from the tables: the loads' registers, and y0 / fy
+	 * in scalar registers.  The table entries themselves are read from LDS one issue ahead (tab_*), so that no row
+	 * waits for an LDS round trip before it can form an address. */
+	Raw      pend[Q][2];                                  /* per channel: the source row output row r's window gains */
+	uint32_t idtq[Q][NW];                                 /* my two pixels of output row r (green and alpha are copied) */
+	int      sy0[Q][2];                                   /* floor of the source row coordinate, per channel (scalar) */
+	double   sfy[Q][2];                                   /* its fraction (scalar) */
+	int      tab_y0[2];
+	double   tab_fy[2];
+	const uint32_t xoffB = (uint32_t)min(x, W - 2) * PB;  /* W >= 2 is guaranteed by the planner */
+	auto table_read = [&](int rr) {
+		rr = min(rr, nrows - 1);
+#pragma unroll
+		for (int c = 0; c < 2; ++c) { tab_y0[c] = row_y0[c][rr]; tab_fy[c] = row_fy[c][rr]; }
+	};
+	auto issue = [&](int k, int rr) {                      /* rows are issued in order: tab_* holds row rr's entries */
 #pragma unroll
 		for (int c = 0; c < 2; ++c) {
-			y0[c] = __builtin_amdgcn_readfirstlane(row_y0[c][r]);
-			fy[c] = row_fy[c][r];
-			cur_row[c] = pend_row[c];
-			cur[c][0] = pend[c][0]; cur[c][1] = pend[c][1];
+			sy0[k][c] = __builtin_amdgcn_readfirstlane(tab_y0[c]);
+			const unsigned long long fb = __builtin_bit_cast(unsigned long long, tab_fy[c]);
+			const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)fb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(fb >> 32));
+			sfy[k][c] = __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 		}
-		/* ---- issue the next row's loads ------------------------------------------------------ */
-		P2 idt_next = idt;
-		if (r + 1 < nrows) {
+		table_read(rr + 1);
+		rr = min(rr, nrows - 1);                          /* past the tile: a harmless repeat, so that the body has no branch */
 #pragma unroll
-			for (int c = 0; c < 2; ++c) {
-				const int y0n = __builtin_amdgcn_readfirstlane(row_y0[c][r + 1]);
-				pend_row[c] = -1;
-				if (y0n == y0[c] + 1) {
-					pend_row[c] = tap_index<T>(y0n, T - 1, H);
-					fetch(c, pend_row[c], pend[c]);
-				}
-			}
-			load_px2<S, NCH>(src + (size_t)(y + 1) * pitch + xoff, idt_next);
-		}
-		/* ---- this row ------------------------------------------------------------------------ */
-		double v[2][2];                                    /* [channel][pixel] */
+		for (int c = 0; c < 2; ++c) fetch(c, tap_index<T>(sy0[k][c], T - 1, H), pend[k][c]);
+		const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(Y0 + rr) * pitchB);
+		if constexpr (al4) load_dwords<NW>(rs, xoffB, so, idtq[k]);
+		else load_halves<2 * NCH>(rs, xoffB, so, idtq[k]);
+	};
+	double hh[2][2][T];                                   /* the horizontally filtered window rows of my two columns, per channel */
+	int    y0prev[2];
+	/* Row 0's windows: all 2 x T source rows are requested at once (one memory latency for the tile's start, not
+	 * 2 x T of them one after the other; every wave of the launch is here at the same time). */
+	{
+		Raw first[2][T];
 #pragma unroll
 		for (int c = 0; c < 2; ++c) {
-			if (y0[c] == y0prev[c] + 1) {
-				/* slide by one source row: row k of the new window is row k + 1 of the old one */
-				const int need = tap_index<T>(y0[c], T - 1, H);
-				if (cur_row[c] != need) fetch(c, need, cur[c]);        /* never in steady state */
+			y0prev[c] = __builtin_amdgcn_readfirstlane(row_y0[c][0]);
+#pragma unroll
+			for (int t = 0; t < T; ++t) fetch(c, tap_index<T>(y0prev[c], t, H), first[c][t]);
+		}
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
 				double nw[2];
-				absorb(c, cur[c], nw);
+				convert(c, first[c][t]);
+				hrow(c, nw);
+				hh[c][0][t] = nw[0]; hh[c][1][t] = nw[1];
+			}
+	}
+	table_read(0);
 #pragma unroll
-				for (int j = 0; j < 2; ++j) {
+	for (int k = 0; k + 1 < Q; ++k) issue(k, k);
+
+	for (int r0 = 0; r0 < nrows; r0 += Q) {
 #pragma unroll
-					for (int t = 0; t + 1 < T; ++t) hh[c][j][t] = hh[c][j][t + 1];
-					hh[c][j][T - 1] = nw[j];
-				}
-			} else if (y0[c] != y0prev[c]) {
-				/* first row of the tile, or a scale step that skips a row: rebuild the window */
+		for (int k = 0; k < Q; ++k) {
+			const int r = r0 + k;                          /* may run up to Q - 1 rows past the tile: those rows store nothing */
+			const bool live = r < nrows;
+			issue((k + Q - 1) % Q, r + Q - 1);            /* into the slot row r - 1 used */
+			const Raw (&cur)[2] = pend[k];
+			uint32_t px[NW];
 #pragma unroll
-				for (int t = 0; t < T; ++t) {
-					S raw[2];
+			for (int i = 0; i < NW; ++i) px[i] = idtq[k][i];
+			const int y0[2] = { sy0[k][0], sy0[k][1] };
+
+			if (__builtin_expect(y0[0] == y0prev[0] + 1 && y0[1] == y0prev[1] + 1, 1)) {
+				/* the usual row: both windows slide by one source row (row t of the new window is row t + 1 of the old
+				 * one).  Both channels' samples go to LDS before either is read back: one round trip, not two. */
+				convert(0, cur[0]);
+				convert(1, cur[1]);
+#pragma unroll
+				for (int c = 0; c < 2; ++c) {
 					double nw[2];
-					fetch(c, tap_index<T>(y0[c], t, H), raw);
-					absorb(c, raw, nw);
-					hh[c][0][t] = nw[0]; hh[c][1][t] = nw[1];
+					hrow(c, nw);
+#pragma unroll
+					for (int j = 0; j < 2; ++j) {
+#pragma unroll
+						for (int t = 0; t + 1 < T; ++t) hh[c][j][t] = hh[c][j][t + 1];
+						hh[c][j][T - 1] = nw[j];
+					}
 				}
-			}                                               /* y0 == y0prev: the same window again */
-			y0prev[c] = y0[c];
-#pragma unroll
-			for (int j = 0; j < 2; ++j) v[c][j] = clip01(vfilter<T>(hh[c][j], fy[c]));   /* clip_d, fix-ca.c:873-880 */
-		}
-		/* green and alpha are copied (fix-ca.c:1098), red and blue replaced */
-		if (act0) {
-			S *out = dst + (size_t)y * pitch + (size_t)x * NCH;
-			if (act1) {
-				P2 px = idt;
-				px.v[0] = C::put(v[0][0]); px.v[2] = C::put(v[1][0]);
-				px.v[NCH] = C::put(v[0][1]); px.v[NCH + 2] = C::put(v[1][1]);
-				store_px2<S, NCH>(out, px);
 			} else {
-				/* the odd last column of an odd-width image: x == W - 1, idt was loaded from column W - 2 */
-				S px[NCH];
 #pragma unroll
-				for (int k = 0; k < NCH; ++k) px[k] = idt.v[NCH + k];
-				px[0] = C::put(v[0][0]); px[2] = C::put(v[1][0]);
+				for (int c = 0; c < 2; ++c) {
+					if (y0[c] == y0prev[c] + 1) {
+						double nw[2];
+						convert(c, cur[c]);
+						hrow(c, nw);
 #pragma unroll
-				for (int k = 0; k < NCH; ++k) out[k] = px[k];
+						for (int j = 0; j < 2; ++j) {
+#pragma unroll
+							for (int t = 0; t + 1 < T; ++t) hh[c][j][t] = hh[c][j][t + 1];
+							hh[c][j][T - 1] = nw[j];
+						}
+					} else if (y0[c] != y0prev[c]) {
+						/* a scale step that skips a row: rebuild the window */
+#pragma unroll
+						for (int t = 0; t < T; ++t) {
+							Raw raw;
+							double nw[2];
+							fetch(c, tap_index<T>(y0[c], t, H), raw);
+							convert(c, raw);
+							hrow(c, nw);
+							hh[c][0][t] = nw[0]; hh[c][1][t] = nw[1];
+						}
+					}                                       /* y0 == y0prev: the same window again */
+				}
+			}
+			y0prev[0] = y0[0]; y0prev[1] = y0[1];
+			double v[2][2];                                /* [channel][pixel] */
+#pragma unroll
+			for (int c = 0; c < 2; ++c)
+#pragma unroll
+				for (int j = 0; j < 2; ++j) v[c][j] = clip_for_put<C::INTEGER>(vfilter<T>(hh[c][j], sfy[k][c]));
+			/* green and alpha are copied (fix-ca.c:1098), red and blue replaced.
+			 * The row offset is added into the per-lane offset and the stores' scalar offset is the constant 0.  With the
+			 * offset in a scalar register the compiler places a VALU write to a 16-byte store's data registers straight
+			 * behind the store (it takes the two issue cycles of such a store as the wait state that overwrite needs);
+			 * on this device that is not enough: the last lanes of each group of 16 were stored with the new value of the
+			 * register (seen as 36 wrong samples in a 6000x4000 RGBA double image).  With a constant offset the compiler
+			 * inserts the wait state itself. */
+			const uint32_t so = (uint32_t)r * pitchB;
+			if constexpr (!ODDW) {
+				set_sample<S>(px, 0, C::put(v[0][0])); set_sample<S>(px, 2, C::put(v[1][0]));
+				set_sample<S>(px, NCH, C::put(v[0][1])); set_sample<S>(px, NCH + 2, C::put(v[1][1]));
+				store_dwords<NW>(rd, (act0 && live) ? (uint32_t)x * PB + so : dst_range, 0, px);
+			} else {
+				/* odd width: the last column's lane has one pixel (x == W - 1; px was loaded from column W - 2, so it is px's second) */
+				const bool lone = act0 && !act1;
+				if (lone) {
+#pragma unroll
+					for (int i = 0; i < NCH; ++i) set_sample<S>(px, i, get_sample<S>(px, NCH + i));
+				}
+				set_sample<S>(px, 0, C::put(v[0][0])); set_sample<S>(px, 2, C::put(v[1][0]));
+				set_sample<S>(px, NCH, C::put(v[0][1])); set_sample<S>(px, NCH + 2, C::put(v[1][1]));
+				const uint32_t o0 = (act0 && live) ? (uint32_t)x * PB + so : dst_range, o1 = (act1 && live) ? (uint32_t)(x + 1) * PB + so : dst_range;
+				if constexpr (ALIGNED) {
+					store_dwords<PB / 4>(rd, o0, 0, px);
+					store_dwords<PB / 4>(rd, o1, 0, px + PB / 4);
+				} else {
+					store_halves<NCH>(rd, o0, 0, px, 0);
+					store_halves<NCH>(rd, o1, 0, px, NCH);
+				}
 			}
 		}
-		idt = idt_next;
 	}
 }
 
+/* the instantiation a geometry runs: sample type x (interpolation, samples per pixel, odd width) */
 template <typename S>
-hipError_t launch_typed(const void *d_src, void *d_dst, const FixcaGeom *g, const WidePlan *wp, hipStream_t stream)
+const void *wcol_kernel(int sel)
 {
-	const S *s = static_cast<const S *>(d_src);
-	S *d = static_cast<S *>(d_dst);
-	const dim3 grid((unsigned)wp->nblocks), block(64);
-	if (g->interp == 2) {
-		if (g->nch == 4) hipLaunchKernelGGL((k_wcol<S, 4, 4>), grid, block, 0, stream, s, d, *g, *wp);
-		else             hipLaunchKernelGGL((k_wcol<S, 3, 4>), grid, block, 0, stream, s, d, *g, *wp);
-	} else {
-		if (g->nch == 4) hipLaunchKernelGGL((k_wcol<S, 4, 2>), grid, block, 0, stream, s, d, *g, *wp);
-		else             hipLaunchKernelGGL((k_wcol<S, 3, 2>), grid, block, 0, stream, s, d, *g, *wp);
+	/* queue slots: 3 where the registers allow it with 3 waves per SIMD (RGBA u16: 162-164), else 2 (measured equal
+	 * within 3 % on RGBA u16; a third slot would push RGBA float and RGB u16 past 168 registers) */
+	constexpr int Q4 = sizeof(S) == 2 ? WIDE_SLOTS : WIDE_SLOTS - 1, Q3 = WIDE_SLOTS - 1;
+	switch (sel) {
+	case 7: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, true>);
+	case 6: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, false>);
+	case 5: return reinterpret_cast<const void *>(&k_wcol<S, 3, 4, Q3, true>);
+	case 4: return reinterpret_cast<const void *>(&k_wcol<S, 3, 4, Q3, false>);
+	case 3: return reinterpret_cast<const void *>(&k_wcol<S, 4, 2, Q4, true>);
+	case 2: return reinterpret_cast<const void *>(&k_wcol<S, 4, 2, Q4, false>);
+	case 1: return reinterpret_cast<const void *>(&k_wcol<S, 3, 2, Q3, true>);
+	default: return reinterpret_cast<const void *>(&k_wcol<S, 3, 2, Q3, false>);
 	}
-	return hipGetLastError();
+}
+int wcol_type_index(int bpc) { return bpc == 2 ? 0 : bpc == 4 ? 1 : bpc == -4 ? 2 : bpc == -8 ? 3 : -1; }
+int wcol_selector(const FixcaGeom *g) { return (g->interp == 2 ? 4 : 0) | (g->nch == 4 ? 2 : 0) | (g->W & 1); }
+const void *wcol_kernel_for(const FixcaGeom *g)
+{
+	const int sel = wcol_selector(g);
+	switch (g->bpc) {
+	case 2:  return wcol_kernel<uint16_t>(sel);
+	case 4:  return wcol_kernel<uint32_t>(sel);
+	case -4: return wcol_kernel<float>(sel);
+	case -8: return wcol_kernel<double>(sel);
+	default: return nullptr;
+	}
 }
 
 }   /* namespace */
+
+/*
+ * Waves of this geometry's kernel the device holds at once (resident waves per CU x CUs), 0 when that cannot be asked
+ * (no device).  The planner sizes the tiles from it: the kernel is bound by fp64 issue, every wave of a launch does
+ * the same work, so the launch is fastest when all tiles are resident together and every SIMD has the same number.
+ */
+extern "C" int
+fixca_wide_slots(const FixcaGeom *g)
+{
+	static std::mutex mu;
+	static int cached[4][8];                              /* 0 = not asked yet, -1 = cannot be asked */
+	const int ti = wcol_type_index(g->bpc);
+	if (ti < 0 || (g->interp != 1 && g->interp != 2)) return 0;
+	const int sel = wcol_selector(g);
+	std::lock_guard<std::mutex> lock(mu);
+	if (cached[ti][sel] == 0) {
+		int per_cu = 0, dev = 0, cus = 0;
+		if (hipGetDevice(&dev) == hipSuccess &&
+		    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+		    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wcol_kernel_for(g), 64, 0) == hipSuccess && per_cu > 0 && cus > 0)
+			cached[ti][sel] = per_cu * cus;
+		else {
+			(void)hipGetLastError();
+			cached[ti][sel] = -1;
+		}
+	}
+	return cached[ti][sel] > 0 ? cached[ti][sel] : 0;
+}
 
 extern "C" hipError_t
 fixca_launch_wide(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
 	if (g->y2 <= g->y1) return hipSuccess;
 	if (g->interp != 1 && g->interp != 2) return hipErrorInvalidValue;
+	const void *fn = wcol_kernel_for(g);
+	if (!fn) return hipErrorInvalidValue;
 	WidePlan wp;
 	wp.oc = pl->oc; wp.th = pl->th; wp.nstrips = pl->nstrips; wp.nwaves = pl->nwaves; wp.nblocks = pl->nblocks;
-	switch (g->bpc) {
-	case 2:  return launch_typed<uint16_t>(d_src, d_dst, g, &wp, stream);
-	case 4:  return launch_typed<uint32_t>(d_src, d_dst, g, &wp, stream);
-	case -4: return launch_typed<float>(d_src, d_dst, g, &wp, stream);
-	case -8: return launch_typed<double>(d_src, d_dst, g, &wp, stream);
-	default: return hipErrorInvalidValue;
-	}
+	FixcaGeom geom = *g;
+	void *args[] = { &d_src, &d_dst, &geom, &wp };
+	return hipLaunchKernel(fn, dim3((unsigned)wp.nblocks), dim3(64), args, 0, stream);
 }

@@ -186,6 +186,30 @@ def _fuzz_cases(n, seed):
     return cases
 
 
+@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1)], ids=str)
+def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
+    """k_wcol against the one-thread-per-pixel kernel (itself checked against the oracle above) on BASELINE's
+    6000x4000: every tile geometry of a real launch, and enough samples for rare hardware races to show
+    (a 16-byte buffer store followed by an overwrite of its data register lost 36 samples of 96 million on
+    RGBA double before the stores were given a constant scalar offset)."""
+    torch = torch_cuda
+    w, h, sb = 6000, 4000, abs(bpc)
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=interp)
+    raw = torch.empty((h, w, nch * sb), dtype=torch.uint8, device="cuda")
+    fixca.noise_fill(raw, 0xF1CA4000 + nch)
+    if bpc == -4:
+        raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
+    if bpc == -8:
+        raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
+    assert "wide-roll" in fixca.plan(w, h, nch * sb, bpc, p)[1]
+    a, b = torch.zeros_like(raw), torch.zeros_like(raw)
+    for _ in range(2):       # twice: the second launch runs against warm caches, other timing
+        fixca.fix_ca_region(raw, a, w, h, nch * sb, bpc, p, 0, w, 0, h, True, fixca.KERNEL_AUTO)
+        fixca.fix_ca_region(raw, b, w, h, nch * sb, bpc, p, 0, w, 0, h, True, fixca.KERNEL_EXACT)
+        torch.cuda.synchronize()
+        assert int((a != b).sum()) == 0
+
+
 @pytest.mark.parametrize("idx", range(60))
 def test_fuzz_auto_kernel_against_oracle(torch_cuda, idx):
     w, h, kw = _fuzz_cases(60, 0xF1CA)[idx]

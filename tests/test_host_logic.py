@@ -113,3 +113,22 @@ def test_host_cache_is_per_thread():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert seen[0] == (None, None, 0) and seen[1] == (None, None, 0)
+
+
+def test_no_store_data_hazard_in_kernels(tmp_path):
+    """A 16-byte buffer store must not be followed directly by a VALU write of its data registers: on MI355X the
+    overwrite reaches the store when the store's scalar offset is a register (tools/store_hazard_scan.py).
+    Compiles the kernels that use buffer stores to assembly with the library's flags and scans them."""
+    import shutil, subprocess, sys, os
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import store_hazard_scan
+    for src in ("fixca_wide.hip", "fixca_roll.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        os.path.join(root, "gimp-fix-ca_amd", "csrc", src), "-o", str(out)], check=True, capture_output=True)
+        direct = [h for h in store_hazard_scan.scan(str(out)) if "(+1)" in h]
+        assert not direct, direct[:3]
