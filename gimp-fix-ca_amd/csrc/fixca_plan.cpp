@@ -465,9 +465,10 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 	if (g->interp == 0 || g->bpc == 1 || g->W < 2) return false;
 	/* the kernel addresses the image through 32-bit buffer offsets: rows below 8 MB, image below 4 GB */
 	if ((long long)g->W * g->bpp >= (8LL << 20) || (long long)g->W * g->bpp * g->H >= (1LL << 32) - 4096) return false;
-	/* the one case where the one-thread-per-pixel kernel measures faster: LINEAR on double samples (no get_pixel
-	 * division to save, 8 loads of 8 bytes per pixel: 396 vs 488 us for 6000x4000 RGBA) */
-	if (g->bpc == -8 && g->interp == 1) return false;
+	/* the one case where the one-thread-per-pixel kernel measures faster: LINEAR on RGB double samples (no get_pixel
+	 * division to save, and 48-byte pixel pairs stored by the lane that computed them; RGBA double moves as 16-byte
+	 * units and is faster here: 328 vs 417 us for 6000x4000) */
+	if (g->bpc == -8 && g->interp == 1 && g->nch != 4) return false;
 	const int taps = (g->interp == 2) ? 4 : 2, back = (taps == 4) ? 1 : 0, W = g->W;
 	const int oc = WIDE_OC;
 	for (int c = 0; c < 2; ++c)

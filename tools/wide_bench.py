@@ -8,7 +8,7 @@ ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, bpc, nch in (("RGBA u16", 2, 4), ("RGBA float", -4, 4), ("RGBA u32", 4, 4), ("RGBA double", -8, 4), ("RGB u16", 2, 3), ("RGB float", -4, 3)):
     if ONLY and ONLY not in name:
         continue
-    for interp in ((2,) if ONLY else (2, 1, 0)):
+    for interp in ((2, 1) if ONLY else (2, 1, 0)):
         p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=interp)
         sb = abs(bpc)
         B = 4
@@ -38,6 +38,6 @@ for name, bpc, nch in (("RGBA u16", 2, 4), ("RGBA float", -4, 4), ("RGBA u32", 4
             if kern == fixca.KERNEL_AUTO:
                 keep = dst[0].clone()
             else:
-                print("      auto == exact on image %d: %s" % ((N - 1) % B, bool(torch.equal(dst[(N - 1) % B], dst[(N - 1) % B]))), "| image 0 identical:", bool(torch.equal(keep, dst[0])))
+                print("      auto == exact on image 0:", bool(torch.equal(keep, dst[0])))
         del raw, dst
         torch.cuda.empty_cache()
