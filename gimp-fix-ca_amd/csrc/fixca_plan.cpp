@@ -462,22 +462,32 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
  * the strip's first column; every tap of every column of the strip must fall inside it */
 static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 {
-	if (g->interp == 0 || g->bpc == 1 || g->W < 2) return false;
+	if (g->bpc == 1 || g->W < 2) return false;
+	/* NONE: the rolling kernel wins on 16-bit samples (6000x4000 RGBA u16 93 vs 129 us, RGB 83 vs 118); on 4- and
+	 * 8-byte samples the one-thread-per-pixel gather is faster (RGBA float 151 vs 189 us, double 315 vs 348) */
+	if (g->interp == 0 && g->bpc != 2) return false;
 	/* the kernel addresses the image through 32-bit buffer offsets: rows below 8 MB, image below 4 GB */
 	if ((long long)g->W * g->bpp >= (8LL << 20) || (long long)g->W * g->bpp * g->H >= (1LL << 32) - 4096) return false;
 	/* the one case where the one-thread-per-pixel kernel measures faster: LINEAR on RGB double samples (no get_pixel
 	 * division to save, and 48-byte pixel pairs stored by the lane that computed them; RGBA double moves as 16-byte
 	 * units and is faster here: 328 vs 417 us for 6000x4000) */
 	if (g->bpc == -8 && g->interp == 1 && g->nch != 4) return false;
-	const int taps = (g->interp == 2) ? 4 : 2, back = (taps == 4) ? 1 : 0, W = g->W;
+	const int taps = (g->interp == 2) ? 4 : (g->interp == 1) ? 2 : 1, back = (taps == 4) ? 1 : 0, W = g->W;
 	const int oc = WIDE_OC;
 	for (int c = 0; c < 2; ++c)
 		for (int X0 = 0; X0 < W; X0 += oc) {
 			/* window origin as the kernel takes it: the strip's lowest tap, unclamped (-1 at the left edge), rounded
-			 * down to even; the clamped taps of the reference are then consecutive window slots (fixca_wide.hip) */
+			 * down to even; the clamped taps of the reference are then consecutive window slots (fixca_wide.hip).
+			 * NONE has one tap, the nearest column (scale(), fix-ca.c:799-809) */
 			const int xl = (X0 + oc < W ? X0 + oc : W) - 1;
-			const int f = ((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back) & ~1;
-			const int l = (int)floor(h_map_dbl(xl, g->xc, W, g->s[c], g->xs[c])) - back + taps - 1;
+			int f, l;
+			if (taps == 1) {
+				f = h_map_int(X0, g->xc, W, g->s[c], g->xs[c]) & ~1;
+				l = h_map_int(xl, g->xc, W, g->s[c], g->xs[c]);
+			} else {
+				f = ((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back) & ~1;
+				l = (int)floor(h_map_dbl(xl, g->xc, W, g->s[c], g->xs[c])) - back + taps - 1;
+			}
 			if (l - f > WIDE_WIN - 1) return false;
 			/* the map is monotone for s > 0, so no column of the strip reaches below f or above l */
 		}
@@ -557,9 +567,9 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	pl->kernel = FIXCA_K_EXACT;
 	if (want == FIXCA_KERNEL_EXACT) return FIXCA_OK;
 	if (g->bpc != 1) {
-		/* 16/32-bit and floating-point samples: the rolling fp64 kernel for LINEAR / CUBIC (bit-exact
-		 * like the one-thread-per-pixel kernel, which stays for NONE, a plain gather, and as the
-		 * fallback for scales that drift more than a window over one strip) */
+		/* 16/32-bit and floating-point samples: the rolling kernel (fp64 for LINEAR / CUBIC, a copy for NONE),
+		 * bit-exact like the one-thread-per-pixel kernel, which stays as the checker and as the fallback
+		 * for scales that drift more than a window over one strip */
 		if (!fixca_debug_flag("FIXCA_NO_WCOL") && plan_wide(g, pl)) return FIXCA_OK;
 		memset(pl, 0, sizeof *pl);
 		pl->kernel = FIXCA_K_EXACT;

@@ -28,6 +28,7 @@
 #include "fixca_device.h"
 #include "fixca_wide.h"
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -247,23 +248,31 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	 * Channel c's window is source columns Uw .. Uw + 127, clamped into the image when they are FETCHED
 	 * (hbuf[i] = sample at clamp(Uw + i, 0, W - 1)): the reference's clamped taps
 	 * clamp(c0 - BACK + t, 0, W - 1) are then hbuf[c0 - BACK - Uw + t] with no clamp, 4 consecutive doubles. */
-	typedef const __attribute__((address_space(3))) double *lds_dp;
-	lds_dp   hb[2][2];                                    /* tap 0 in hbuf, per channel and pixel */
+	/* what the wave exchanges through LDS: get_pixel's doubles for the filters, the samples themselves for NONE */
+	typedef typename std::conditional<T == 1, S, double>::type X;
+	typedef const __attribute__((address_space(3))) X *lds_xp;
+	X *const xbuf = reinterpret_cast<X *>(&hbuf[0][0]);
+	lds_xp   hb[2][2];                                    /* tap 0 in the exchange buffer, per channel and pixel */
 	uint32_t wcol[2][2];                                  /* byte offset in a row of the sample (or pair) this lane fetches */
 	int      sel[2][2];                                   /* PAIRWIN: which pixel of the fetched pair is window column 2 * lane + j */
 	double   fx[2][2];
 #pragma unroll
 	for (int c = 0; c < 2; ++c) {
-		const double xd0 = map_dbl(X0, g.xc, W, g.s[c], g.xs[c]);
-		const int Uw = __builtin_amdgcn_readfirstlane(((int)floor(xd0) - BACK) & ~1);   /* the strip's first column has the lowest tap (the map is monotone); may be -2 */
+		/* T == 1 (NONE): the one tap is the nearest source column, scale() of fix-ca.c:799-809 */
+		const int first_tap = (T == 1) ? map_int(X0, g.xc, W, g.s[c], g.xs[c]) : (int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK;
+		const int Uw = __builtin_amdgcn_readfirstlane(first_tap & ~1);   /* the strip's first column has the lowest tap (the map is monotone); may be -2 */
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			const int xx = min(x + j, W - 1);
-			const double xd = map_dbl(xx, g.xc, W, g.s[c], g.xs[c]);
-			const int c0 = (int)floor(xd);
-			fx[c][j] = __dsub_rn(xd, (double)c0);
+			int c0;
+			if constexpr (T == 1) { c0 = map_int(xx, g.xc, W, g.s[c], g.xs[c]); fx[c][j] = 0.0; }
+			else {
+				const double xd = map_dbl(xx, g.xc, W, g.s[c], g.xs[c]);
+				c0 = (int)floor(xd);
+				fx[c][j] = __dsub_rn(xd, (double)c0);
+			}
 			const int b = max(0, min(c0 - BACK - Uw, WIDE_WIN - T));              /* the planner guarantees the range */
-			hb[c][j] = (lds_dp)&hbuf[c][0] + b;
+			hb[c][j] = (lds_xp)&xbuf[c * WIDE_WIN] + b;
 		}
 		const int col0 = max(0, min(Uw + 2 * lane, W - 1)), col1 = max(0, min(Uw + 2 * lane + 1, W - 1));
 		if constexpr (PAIRWIN && al4) {
@@ -304,18 +313,20 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 				for (int i = 0; i < RW; ++i) asm volatile("" :: "v"(raw.w[i]));
 			} else { s[0] = (S)raw.w[0]; s[1] = (S)raw.w[1]; }
 		} else { s[0] = get_sample<S>(raw.w, 0); s[1] = get_sample<S>(raw.w, 1); }
-		hbuf[c][2 * lane] = C::get(s[0]);
-		hbuf[c][2 * lane + 1] = C::get(s[1]);
+		if constexpr (T == 1) { xbuf[c * WIDE_WIN + 2 * lane] = s[0]; xbuf[c * WIDE_WIN + 2 * lane + 1] = s[1]; }
+		else { xbuf[c * WIDE_WIN + 2 * lane] = C::get(s[0]); xbuf[c * WIDE_WIN + 2 * lane + 1] = C::get(s[1]); }
 	};
 	/* the horizontal filter of my two columns on the row in hbuf[c].  One wave: its LDS operations complete in order,
 	 * the reads see the writes of convert() */
 	auto hrow = [&](int c, double (&out)[2]) {
+		if constexpr (T > 1) {
 #pragma unroll
-		for (int j = 0; j < 2; ++j) {
-			double p[T];
+			for (int j = 0; j < 2; ++j) {
+				double p[T];
 #pragma unroll
-			for (int t = 0; t < T; ++t) p[t] = hb[c][j][t];
-			out[j] = hfilter<T>(p, fx[c][j]);
+				for (int t = 0; t < T; ++t) p[t] = hb[c][j][t];
+				out[j] = hfilter<T>(p, fx[c][j]);
+			}
 		}
 	};
 	/* The row coordinates are the same for every lane: lane L computes those of row Y0 + L (and
@@ -323,10 +334,15 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	for (int i = lane; i < nrows; i += 64) {
 #pragma unroll
 		for (int c = 0; c < 2; ++c) {
-			const double yd = map_dbl(Y0 + i, g.yc, H, g.s[c], g.ys[c]);
-			const int y0 = (int)floor(yd);
-			row_y0[c][i] = y0;
-			row_fy[c][i] = __dsub_rn(yd, (double)y0);
+			if constexpr (T == 1) {
+				row_y0[c][i] = map_int(Y0 + i, g.yc, H, g.s[c], g.ys[c]);     /* nearest source row (fix-ca.c:1105-1106) */
+				row_fy[c][i] = 0.0;
+			} else {
+				const double yd = map_dbl(Y0 + i, g.yc, H, g.s[c], g.ys[c]);
+				const int y0 = (int)floor(yd);
+				row_y0[c][i] = y0;
+				row_fy[c][i] = __dsub_rn(yd, (double)y0);
+			}
 		}
 	}
 
@@ -372,7 +388,7 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	int    y0prev[2];
 	/* Row 0's windows: all 2 x T source rows are requested at once (one memory latency for the tile's start, not
 	 * 2 x T of them one after the other; every wave of the launch is here at the same time). */
-	{
+	if constexpr (T > 1) {
 		Raw first[2][T];
 #pragma unroll
 		for (int c = 0; c < 2; ++c) {
@@ -406,28 +422,25 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 			for (int i = 0; i < NW; ++i) px[i] = idtq[k][i];
 			const int y0[2] = { sy0[k][0], sy0[k][1] };
 
-			if (__builtin_expect(y0[0] == y0prev[0] + 1 && y0[1] == y0prev[1] + 1, 1)) {
-				/* the usual row: both windows slide by one source row (row t of the new window is row t + 1 of the old
-				 * one).  Both channels' samples go to LDS before either is read back: one round trip, not two. */
+			S outv[2][2];                                  /* [channel][pixel]: the samples to store */
+			if constexpr (T == 1) {
+				/* NONE (fix-ca.c:1100-1121): the sample of the nearest source position, copied as it is.  The queue holds
+				 * the source row of each channel; every lane picks its two samples out of the row the wave laid out in LDS. */
 				convert(0, cur[0]);
 				convert(1, cur[1]);
 #pragma unroll
-				for (int c = 0; c < 2; ++c) {
-					double nw[2];
-					hrow(c, nw);
+				for (int c = 0; c < 2; ++c)
 #pragma unroll
-					for (int j = 0; j < 2; ++j) {
-#pragma unroll
-						for (int t = 0; t + 1 < T; ++t) hh[c][j][t] = hh[c][j][t + 1];
-						hh[c][j][T - 1] = nw[j];
-					}
-				}
+					for (int j = 0; j < 2; ++j) outv[c][j] = hb[c][j][0];
 			} else {
+				if (__builtin_expect(y0[0] == y0prev[0] + 1 && y0[1] == y0prev[1] + 1, 1)) {
+					/* the usual row: both windows slide by one source row (row t of the new window is row t + 1 of the old
+					 * one).  Both channels' samples go to LDS before either is read back: one round trip, not two. */
+					convert(0, cur[0]);
+					convert(1, cur[1]);
 #pragma unroll
-				for (int c = 0; c < 2; ++c) {
-					if (y0[c] == y0prev[c] + 1) {
+					for (int c = 0; c < 2; ++c) {
 						double nw[2];
-						convert(c, cur[c]);
 						hrow(c, nw);
 #pragma unroll
 						for (int j = 0; j < 2; ++j) {
@@ -435,26 +448,45 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 							for (int t = 0; t + 1 < T; ++t) hh[c][j][t] = hh[c][j][t + 1];
 							hh[c][j][T - 1] = nw[j];
 						}
-					} else if (y0[c] != y0prev[c]) {
-						/* a scale step that skips a row: rebuild the window */
+					}
+				} else {
 #pragma unroll
-						for (int t = 0; t < T; ++t) {
-							Raw raw;
+					for (int c = 0; c < 2; ++c) {
+						if (y0[c] == y0prev[c] + 1) {
 							double nw[2];
-							fetch(c, tap_index<T>(y0[c], t, H), raw);
-							convert(c, raw);
+							convert(c, cur[c]);
 							hrow(c, nw);
-							hh[c][0][t] = nw[0]; hh[c][1][t] = nw[1];
-						}
-					}                                       /* y0 == y0prev: the same window again */
+#pragma unroll
+							for (int j = 0; j < 2; ++j) {
+#pragma unroll
+								for (int t = 0; t + 1 < T; ++t) hh[c][j][t] = hh[c][j][t + 1];
+								hh[c][j][T - 1] = nw[j];
+							}
+						} else if (y0[c] != y0prev[c]) {
+							/* a scale step that skips a row: rebuild the window */
+#pragma unroll
+							for (int t = 0; t < T; ++t) {
+								Raw raw;
+								double nw[2];
+								fetch(c, tap_index<T>(y0[c], t, H), raw);
+								convert(c, raw);
+								hrow(c, nw);
+								hh[c][0][t] = nw[0]; hh[c][1][t] = nw[1];
+							}
+						}                                       /* y0 == y0prev: the same window again */
+					}
 				}
+				y0prev[0] = y0[0]; y0prev[1] = y0[1];
+				double v[2][2];                                /* [channel][pixel] */
+#pragma unroll
+				for (int c = 0; c < 2; ++c)
+#pragma unroll
+					for (int j = 0; j < 2; ++j) v[c][j] = clip_for_put<C::INTEGER>(vfilter<T>(hh[c][j], sfy[k][c]));
+#pragma unroll
+				for (int c = 0; c < 2; ++c)
+#pragma unroll
+					for (int j = 0; j < 2; ++j) outv[c][j] = C::put(v[c][j]);
 			}
-			y0prev[0] = y0[0]; y0prev[1] = y0[1];
-			double v[2][2];                                /* [channel][pixel] */
-#pragma unroll
-			for (int c = 0; c < 2; ++c)
-#pragma unroll
-				for (int j = 0; j < 2; ++j) v[c][j] = clip_for_put<C::INTEGER>(vfilter<T>(hh[c][j], sfy[k][c]));
 			/* green and alpha are copied (fix-ca.c:1098), red and blue replaced.
 			 * The row offset is added into the per-lane offset and the stores' scalar offset is the constant 0.  With the
 			 * offset in a scalar register the compiler places a VALU write to a 16-byte store's data registers straight
@@ -468,8 +500,8 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 				 * convert(); a wave's LDS operations complete in order); then each lane picks up the red and blue of the units
 				 * it holds: unit = pixel for 16-byte pixels; for 32-byte pixels even units are (R, G), odd ones (B, A) */
 				S *res = reinterpret_cast<S *>(&hbuf[0][0]);
-				res[4 * lane + 0] = C::put(v[0][0]); res[4 * lane + 1] = C::put(v[1][0]);
-				res[4 * lane + 2] = C::put(v[0][1]); res[4 * lane + 3] = C::put(v[1][1]);
+				res[4 * lane + 0] = outv[0][0]; res[4 * lane + 1] = outv[1][0];
+				res[4 * lane + 2] = outv[0][1]; res[4 * lane + 3] = outv[1][1];
 				const rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(dst) + (size_t)(Y0 + min(r, nrows - 1)) * pitchB, 0,
 				                                                      live ? pitchB : 0u, 0x00020000);
 #pragma unroll
@@ -482,8 +514,8 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 				}
 			} else
 			if constexpr (!ODDW) {
-				set_sample<S>(px, 0, C::put(v[0][0])); set_sample<S>(px, 2, C::put(v[1][0]));
-				set_sample<S>(px, NCH, C::put(v[0][1])); set_sample<S>(px, NCH + 2, C::put(v[1][1]));
+				set_sample<S>(px, 0, outv[0][0]); set_sample<S>(px, 2, outv[1][0]);
+				set_sample<S>(px, NCH, outv[0][1]); set_sample<S>(px, NCH + 2, outv[1][1]);
 				store_dwords<NW>(rd, (act0 && live) ? (uint32_t)x * PB + so : dst_range, 0, px);
 			} else {
 				/* odd width: the last column's lane has one pixel (x == W - 1; px was loaded from column W - 2, so it is px's second) */
@@ -492,8 +524,8 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 #pragma unroll
 					for (int i = 0; i < NCH; ++i) set_sample<S>(px, i, get_sample<S>(px, NCH + i));
 				}
-				set_sample<S>(px, 0, C::put(v[0][0])); set_sample<S>(px, 2, C::put(v[1][0]));
-				set_sample<S>(px, NCH, C::put(v[0][1])); set_sample<S>(px, NCH + 2, C::put(v[1][1]));
+				set_sample<S>(px, 0, outv[0][0]); set_sample<S>(px, 2, outv[1][0]);
+				set_sample<S>(px, NCH, outv[0][1]); set_sample<S>(px, NCH + 2, outv[1][1]);
 				const uint32_t o0 = (act0 && live) ? (uint32_t)x * PB + so : dst_range, o1 = (act1 && live) ? (uint32_t)(x + 1) * PB + so : dst_range;
 				if constexpr (ALIGNED) {
 					store_dwords<PB / 4>(rd, o0, 0, px);
@@ -515,18 +547,22 @@ const void *wcol_kernel(int sel)
 	 * within 3 % on RGBA u16; a third slot would push RGBA float and RGB u16 past 168 registers) */
 	constexpr int Q4 = sizeof(S) == 2 ? WIDE_SLOTS : WIDE_SLOTS - 1, Q3 = WIDE_SLOTS - 1;
 	switch (sel) {
-	case 7: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, true>);
-	case 6: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, false>);
-	case 5: return reinterpret_cast<const void *>(&k_wcol<S, 3, 4, Q3, true>);
-	case 4: return reinterpret_cast<const void *>(&k_wcol<S, 3, 4, Q3, false>);
-	case 3: return reinterpret_cast<const void *>(&k_wcol<S, 4, 2, Q4, true>);
-	case 2: return reinterpret_cast<const void *>(&k_wcol<S, 4, 2, Q4, false>);
-	case 1: return reinterpret_cast<const void *>(&k_wcol<S, 3, 2, Q3, true>);
-	default: return reinterpret_cast<const void *>(&k_wcol<S, 3, 2, Q3, false>);
+	case 11: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, true>);
+	case 10: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, false>);
+	case 9:  return reinterpret_cast<const void *>(&k_wcol<S, 3, 4, Q3, true>);
+	case 8:  return reinterpret_cast<const void *>(&k_wcol<S, 3, 4, Q3, false>);
+	case 7:  return reinterpret_cast<const void *>(&k_wcol<S, 4, 2, Q4, true>);
+	case 6:  return reinterpret_cast<const void *>(&k_wcol<S, 4, 2, Q4, false>);
+	case 5:  return reinterpret_cast<const void *>(&k_wcol<S, 3, 2, Q3, true>);
+	case 4:  return reinterpret_cast<const void *>(&k_wcol<S, 3, 2, Q3, false>);
+	case 3:  return reinterpret_cast<const void *>(&k_wcol<S, 4, 1, WIDE_SLOTS, true>);
+	case 2:  return reinterpret_cast<const void *>(&k_wcol<S, 4, 1, WIDE_SLOTS, false>);
+	case 1:  return reinterpret_cast<const void *>(&k_wcol<S, 3, 1, WIDE_SLOTS, true>);
+	default: return reinterpret_cast<const void *>(&k_wcol<S, 3, 1, WIDE_SLOTS, false>);
 	}
 }
 int wcol_type_index(int bpc) { return bpc == 2 ? 0 : bpc == 4 ? 1 : bpc == -4 ? 2 : bpc == -8 ? 3 : -1; }
-int wcol_selector(const FixcaGeom *g) { return (g->interp == 2 ? 4 : 0) | (g->nch == 4 ? 2 : 0) | (g->W & 1); }
+int wcol_selector(const FixcaGeom *g) { return 4 * g->interp + (g->nch == 4 ? 2 : 0) + (g->W & 1); }     /* interp 0, 1, 2 */
 const void *wcol_kernel_for(const FixcaGeom *g)
 {
 	const int sel = wcol_selector(g);
@@ -550,9 +586,9 @@ extern "C" int
 fixca_wide_slots(const FixcaGeom *g)
 {
 	static std::mutex mu;
-	static int cached[4][8];                              /* 0 = not asked yet, -1 = cannot be asked */
+	static int cached[4][12];                              /* 0 = not asked yet, -1 = cannot be asked */
 	const int ti = wcol_type_index(g->bpc);
-	if (ti < 0 || (g->interp != 1 && g->interp != 2)) return 0;
+	if (ti < 0 || g->interp < 0 || g->interp > 2) return 0;
 	const int sel = wcol_selector(g);
 	std::lock_guard<std::mutex> lock(mu);
 	if (cached[ti][sel] == 0) {
@@ -573,7 +609,7 @@ extern "C" hipError_t
 fixca_launch_wide(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
 	if (g->y2 <= g->y1) return hipSuccess;
-	if (g->interp != 1 && g->interp != 2) return hipErrorInvalidValue;
+	if (g->interp < 0 || g->interp > 2) return hipErrorInvalidValue;
 	const void *fn = wcol_kernel_for(g);
 	if (!fn) return hipErrorInvalidValue;
 	WidePlan wp;

@@ -80,11 +80,17 @@ def test_plan_refuses_formats_and_domain():
         with pytest.raises(fixca.FixCaError) as e:
             fixca.plan(32, 16, bytes_, bpc, p)
         assert e.value.code == fixca.E_UNSUPPORTED
-    for bytes_, bpc in ((8, 2), (6, 2), (16, 4), (16, -4), (12, -4), (32, -8)):     # u16, u32, float, double: fp64 kernel
+    for bytes_, bpc in ((8, 2), (6, 2), (16, 4), (16, -4), (12, -4), (32, -8)):     # u16, u32, float, double
         k, desc = fixca.plan(32, 16, bytes_, bpc, p)
-        assert k == 1 and "bpc=%d" % bpc in desc
+        assert k == (7 if bpc == 2 else 1) and "bpc=%d" % bpc in desc   # NONE: the rolling kernel on 16-bit samples only
+        assert fixca.plan(32, 16, bytes_, bpc, fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8, interpolation=2))[0] == 7
+        k, desc = fixca.plan(32, 16, bytes_, bpc, p, kernel=fixca.KERNEL_EXACT)
+        assert k == 1 and "bpc=%d" % bpc in desc                     # the one-thread-per-pixel fp64 kernel
+        # a scale that drifts more than a window over one strip: only the one-thread-per-pixel kernel is left
+        far = fixca.make_params(blue=-29.0, red=29.0, lens_x=600, lens_y=8, interpolation=2)
+        assert fixca.plan(1200, 16, bytes_ // abs(bpc) * abs(bpc), bpc, far)[0] == 1
         with pytest.raises(fixca.FixCaError) as e:
-            fixca.plan(32, 16, bytes_, bpc, p, kernel=fixca.KERNEL_FAST)
+            fixca.plan(1200, 16, bytes_, bpc, far, kernel=fixca.KERNEL_FAST)
         assert e.value.code == fixca.E_UNSUPPORTED
     with pytest.raises(fixca.FixCaError) as e:      # max_dim 16 + (-20) <= 0
         fixca.plan(32, 16, 4, 1, fixca.make_params(blue=-20, lens_x=16, lens_y=8))

@@ -186,7 +186,7 @@ def _fuzz_cases(n, seed):
     return cases
 
 
-@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1)], ids=str)
+@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0)], ids=str)
 def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
     """k_wcol against the one-thread-per-pixel kernel (itself checked against the oracle above) on BASELINE's
     6000x4000: every tile geometry of a real launch, and enough samples for rare hardware races to show
