@@ -216,7 +216,13 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	 * (float), 659 -> 228 us (double) with the stores taken out.)  The red and blue results reach the lane that
 	 * stores them through LDS. */
 	constexpr bool FLAT = NCH == 4 && SB >= 4;
-	constexpr int NU = FLAT ? NW / 4 : 1;                 /* 16-byte units per lane and row */
+	/* RGB pixels of 12 or 24 bytes move as 16-byte units too; a unit then holds parts of two pixels, so the whole output
+	 * row of the strip is put together in LDS: the units as loaded, my four results over them, the units read back. */
+	constexpr bool STAGED = NCH == 3 && SB >= 4;
+	constexpr bool UNITS = FLAT || STAGED;
+	constexpr int NU = UNITS ? (WIDE_OC * PB / 16 + 63) / 64 : 1;   /* 16-byte units per lane and row */
+	constexpr int IQ = UNITS ? 4 * NU : NW;               /* dwords a queue slot keeps of the output row */
+	__shared__ uint32_t rowbuf[STAGED ? NU * 64 * 4 : 1];
 	__shared__ double hbuf[2][WIDE_WIN];                  /* one source row's converted samples per channel */
 	__shared__ double row_fy[2][WIDE_TH_MAX];             /* per output row of the tile: fraction ...       */
 	__shared__ int    row_y0[2][WIDE_TH_MAX];             /* ... and floor of the source coordinate          */
@@ -238,11 +244,14 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<S *>(src), 0, (uint32_t)H * pitchB, 0x00020000);
 	const uint32_t dst_range = (uint32_t)nrows * pitchB;  /* also the offset that makes a lane's store a no-op */
 	const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(dst) + (size_t)Y0 * pitchB, 0, dst_range, 0x00020000);
-	/* FLAT: byte offset in a row of this lane's first unit; its stores' offsets (out of the row for units past the strip) */
+	/* UNITS: byte offset in a row of this lane's first unit; its stores' offsets (out of the row for units that are not
+	 * wholly inside the strip: = the row descriptor's size, out of range, and no 32-bit wrap when the access size is added) */
 	const uint32_t ubase = (uint32_t)X0 * PB + 16u * lane;
 	uint32_t ustore[NU];
 #pragma unroll
-	for (int i = 0; i < NU; ++i) ustore[i] = (lane + 64 * i) * 16 < (xe - X0) * PB ? ubase + 1024u * i : pitchB;   /* = the row descriptor's size: out of range, and no 32-bit wrap when the access size is added */
+	for (int i = 0; i < NU; ++i) ustore[i] = (lane + 64 * i) * 16 + 16 <= (xe - X0) * PB ? ubase + 1024u * i : pitchB;
+	/* the strip's bytes need not be whole units (RGB, last strip): the unit they end in, and how many dwords of it are the strip's */
+	const int tail_unit = (xe - X0) * PB / 16, tail_dwords = (xe - X0) * PB % 16 / 4;
 
 	/* ---- per-lane column constants ------------------------------------------------------------
 	 * Channel c's window is source columns Uw .. Uw + 127, clamped into the image when they are FETCHED
@@ -351,7 +360,7 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	 * in scalar registers.  The table entries themselves are read from LDS one issue ahead (tab_*), so that no row
 	 * waits for an LDS round trip before it can form an address. */
 	Raw      pend[Q][2];                                  /* per channel: the source row output row r's window gains */
-	uint32_t idtq[Q][NW];                                 /* my two pixels of output row r (green and alpha are copied) */
+	uint32_t idtq[Q][IQ];                                 /* my two pixels of output row r (green and alpha are copied), or my units of it */
 	int      sy0[Q][2];                                   /* floor of the source row coordinate, per channel (scalar) */
 	double   sfy[Q][2];                                   /* its fraction (scalar) */
 	int      tab_y0[2];
@@ -375,7 +384,7 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 #pragma unroll
 		for (int c = 0; c < 2; ++c) fetch(c, tap_index<T>(sy0[k][c], T - 1, H), pend[k][c]);
 		const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)(Y0 + rr) * pitchB);
-		if constexpr (FLAT) {
+		if constexpr (UNITS) {
 			/* a descriptor of the row alone: units past the end of the row (last strip) read as 0 instead of running into
 			 * the next row, or past the image on its last row */
 			const rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(reinterpret_cast<const uint8_t *>(src)) + (size_t)so, 0, pitchB, 0x00020000);
@@ -417,9 +426,9 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 			const bool live = r < nrows;
 			issue((k + Q - 1) % Q, r + Q - 1);            /* into the slot row r - 1 used */
 			const Raw (&cur)[2] = pend[k];
-			uint32_t px[NW];
+			uint32_t px[IQ];
 #pragma unroll
-			for (int i = 0; i < NW; ++i) px[i] = idtq[k][i];
+			for (int i = 0; i < IQ; ++i) px[i] = idtq[k][i];
 			const int y0[2] = { sy0[k][0], sy0[k][1] };
 
 			S outv[2][2];                                  /* [channel][pixel]: the samples to store */
@@ -511,6 +520,37 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 					if constexpr (SB == 4) { set_sample<S>(px, 4 * i, res[2 * u]); set_sample<S>(px, 4 * i + 2, res[2 * u + 1]); }
 					else set_sample<S>(px, 2 * i, res[u]);
 					store_dwords<4>(rrow, ustore[i], 0, px + 4 * i);
+				}
+			} else if constexpr (STAGED) {
+				const rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(dst) + (size_t)(Y0 + min(r, nrows - 1)) * pitchB, 0,
+				                                                      live ? pitchB : 0u, 0x00020000);
+				/* the three steps touch the same LDS bytes as dwords and as samples: the empty asm statements keep the compiler
+				 * from reordering them (it orders accesses by type); the wave's LDS operations themselves complete in order */
+#pragma unroll
+				for (int i = 0; i < NU; ++i)
+#pragma unroll
+					for (int d = 0; d < 4; ++d) rowbuf[(lane + 64 * i) * 4 + d] = px[4 * i + d];
+				asm volatile("" ::: "memory");
+				S *rowS = reinterpret_cast<S *>(&rowbuf[0]);
+				rowS[(2 * lane) * 3 + 0] = outv[0][0]; rowS[(2 * lane) * 3 + 2] = outv[1][0];
+				rowS[(2 * lane + 1) * 3 + 0] = outv[0][1]; rowS[(2 * lane + 1) * 3 + 2] = outv[1][1];
+				asm volatile("" ::: "memory");
+#pragma unroll
+				for (int i = 0; i < NU; ++i) {
+#pragma unroll
+					for (int d = 0; d < 4; ++d) px[4 * i + d] = rowbuf[(lane + 64 * i) * 4 + d];
+					store_dwords<4>(rrow, ustore[i], 0, px + 4 * i);
+				}
+				asm volatile("" ::: "memory");
+				if (tail_dwords) {                          /* wave-uniform: the last strip of an image whose width is not a multiple of 4 */
+#pragma unroll
+					for (int i = 0; i < NU; ++i)
+						if (tail_unit / 64 == i) {
+							const uint32_t o = (lane == tail_unit % 64) ? ubase + 1024u * i : pitchB;
+#pragma unroll
+							for (int d = 0; d < 3; ++d)
+								if (d < tail_dwords) store_dwords<1>(rrow, o == pitchB ? pitchB : o + 4 * d, 0, px + 4 * i + d);
+						}
 				}
 			} else
 			if constexpr (!ODDW) {
