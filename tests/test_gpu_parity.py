@@ -6,6 +6,8 @@ Bars: interpolation NONE bit-exact on every kernel; the fp64 kernel bit-exact in
 all three modes; the fast LINEAR/CUBIC kernel within 1 LSB per 8-bit channel
 (BASELINE.json north_star), green/alpha always exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -361,6 +363,37 @@ def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
         assert got[y1:y2].tobytes() == ref.view(np.uint8).reshape(h, w, nch * sb)[y1:y2].tobytes(), (desc, kw)
         assert np.all(got[:y1] == 0x6B) and np.all(got[y2:] == 0x6B)
     assert seen <= {1, 7}
+
+
+@pytest.mark.parametrize("idx", range(int(os.environ.get("FIXCA_FUZZ_N", "32"))))
+def test_fuzz_wide_any_width(torch_cuda, idx):
+    """the wide sample types on images of ANY width from 2 pixels up (odd widths, RGB rows that do not end on a
+    16-byte unit, strips of a few columns) and heights from 1 row: bit for bit the oracle in all three modes"""
+    torch = torch_cuda
+    rng = np.random.default_rng(0xF1CA0000 + idx)
+    w = int(rng.integers(2, 40)) if idx % 4 == 0 else int(rng.integers(40, 800))
+    h = int(rng.integers(1, 70))
+    mag = [0.3, 2.0, 8.0, 30.0][idx % 4]
+    kw = dict(blue=float(rng.uniform(-mag, mag)), red=float(rng.uniform(-mag, mag)),
+              lens_x=float(rng.integers(-2, w + 2)), lens_y=float(rng.integers(-2, h + 2)),
+              x_blue=float(rng.uniform(-mag, mag)) if idx % 3 == 0 else 0.0, y_red=float(rng.uniform(-mag, mag)) if idx % 5 == 0 else 0.0)
+    bpc, dtype = WIDE[(idx // 2) % 4]
+    nch = 3 if idx % 2 else 4
+    sb = abs(bpc)
+    img = _wide_image(dtype, w, h, nch, 9000 + idx)
+    for interp in (0, 1, 2):
+        p = fixca.make_params(interpolation=interp, **kw)
+        try:
+            kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
+        except fixca.FixCaError as e:
+            assert e.code == fixca.E_DOMAIN
+            continue
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
+        src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+        dst = torch.full_like(src, 0x6B)
+        fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+        torch.cuda.synchronize()
+        assert dst.cpu().numpy().tobytes() == ref.view(np.uint8).tobytes(), (desc, w, h, kw)
 
 
 @pytest.mark.parametrize("bpc,dtype", [(1, np.uint8)] + WIDE, ids=lambda v: str(v))
