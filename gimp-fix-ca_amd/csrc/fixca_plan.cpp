@@ -399,6 +399,10 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			 * waves (4 x the rows a wave keeps alive, so the halo stays ~20 %) measure best:
 			 * 6000x4000, span 7: th 33 -> 35.2 us per image, 44 -> 36.0, 57 -> 37.4 */
 			best_th = 4 * span + 5;
+			/* RGB8 rows are 3/4 of the bytes for the same per-row work: shorter waves (more of them in flight per byte)
+			 * measure 0.7-0.9 points better on one allocation (tools/ab_rgb.py: th 21 65.3 %, 25 65.1, 29 64.5, 33 64.4,
+			 * 41 63.7, 57 60.0) */
+			if (g->bpp == 3) best_th = 3 * span + 4;
 			if (best_th < 24) best_th = 24;
 			if (best_th > 128) best_th = 128;
 		}
