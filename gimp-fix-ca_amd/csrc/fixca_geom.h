@@ -37,6 +37,8 @@ struct FixcaPlan {
 	int ring;           /* kernels 4,5: source rows in the LDS ring            */
 	int ablate;         /* timing experiments only (FIXCA_ABLATE): 1 = skip the filter
 	                       arithmetic, 2 = skip the counted waits; results are wrong */
+	int wide_fast;      /* kernel 7, 16-bit samples, CUBIC: the weight form with exact recomputation of the
+	                       samples near a rounding boundary (fixca_wide.hip); 0 = operation for operation */
 };
 
 #define FIXCA_K_EXACT   1

@@ -464,6 +464,31 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
 
 /* k_wcol gives every channel its own 128-column window starting at the (even-rounded) first tap of
  * the strip's first column; every tap of every column of the strip must fall inside it */
+/* 16-bit CUBIC: may k_wcol use the weight form (fixca_wide.hip)?  Its results are the reference's for every input; what
+ * is decided here is only speed: a sample whose value is within 1e-6 of k + 1/2 is recomputed operation for operation,
+ * and such samples are common exactly when the fractions of the source coordinates sit on a coarse dyadic grid in both
+ * directions (pure shifts by halves, quarters or eighths: with fx = 1/2, fy = 0 every 16th sample is an exact k + 1/2).
+ * Scales other than 1 spread the fractions over the columns and rows and such samples are a few per image. */
+static bool wide_fast_ok(const FixcaGeom *g)
+{
+	if (g->bpc != 2 || g->interp != 2 || fixca_debug_flag("FIXCA_WCOL_REF")) return false;
+	if (fixca_debug_flag("FIXCA_WCOL_WEIGHTS")) return true;          /* tests: the recomputation path under load */
+	const int rows = g->y2 - g->y1;
+	for (int c = 0; c < 2; ++c) {
+		long coarse[2] = { 0, 0 }, zero[2] = { 0, 0 };
+		for (int d = 0; d < 2; ++d) {
+			const int lo = d ? g->y1 : 0, hi = d ? g->y2 : g->W;
+			for (int i = lo; i < hi; ++i) {
+				const double v = d ? h_map_dbl(i, g->yc, g->H, g->s[c], g->ys[c]) : h_map_dbl(i, g->xc, g->W, g->s[c], g->xs[c]);
+				const double f8 = (v - floor(v)) * 8.0, dist = fabs(f8 - floor(f8 + 0.5));
+				if (dist < 1e-4) { if (floor(f8 + 0.5) == 0.0 || floor(f8 + 0.5) == 8.0) ++zero[d]; else ++coarse[d]; }
+			}
+		}
+		if ((coarse[0] * 8 > g->W && (coarse[1] + zero[1]) * 8 > rows) || (coarse[1] * 8 > rows && (coarse[0] + zero[0]) * 8 > g->W)) return false;
+	}
+	return true;
+}
+
 static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 {
 	if (g->bpc == 1 || g->W < 2) return false;
@@ -497,6 +522,7 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 		}
 	pl->kernel = FIXCA_K_WCOL;
 	pl->oc = oc;
+	pl->wide_fast = wide_fast_ok(g) ? 1 : 0;
 	/* Tile height: all tiles resident at once, the same number on every SIMD.  The kernel is bound by fp64 issue and its
 	 * waves all do the same work, so a launch lasts as long as its fullest SIMD (6000x4000 RGBA u16, 3 resident waves
 	 * per SIMD: th 66 -> 3050 waves 132 us; th 60 -> 3350 waves 164 us; th 90 -> 2250 waves 170 us).  Several rounds
@@ -504,7 +530,7 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 	 * atomic queue (evens out the SIMDs, but a tile's start costs as much as 19 rows: 184-250 us). */
 	{
 		const int q = WIDE_SLOTS * (WIDE_SLOTS - 1), th_max = WIDE_TH_MAX / q * q, rows = g->y2 - g->y1, nstrips = (W + oc - 1) / oc;
-		int slots = fixca_wide_slots(g);
+		int slots = fixca_wide_slots(g, pl->wide_fast);
 		if (slots <= 0) slots = 12 * 256;                  /* no device to ask (planning on a CPU-only machine) */
 		const int per_round = slots / nstrips > 0 ? slots / nstrips : 1;
 		int th = (rows + per_round - 1) / per_round;
@@ -531,7 +557,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_WCOL", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH", "FIXCA_ABLATE" };
 
 static void env_signature(char *buf, size_t n)
@@ -625,8 +651,8 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 	if (pl->kernel == FIXCA_K_EXACT)
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d grid=%dx%d", kn[1], in[g->interp], g->bpp, g->bpc, (g->W + 255) / 256, g->y2 - g->y1);
 	else if (pl->kernel == FIXCA_K_WCOL)
-		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d strips=%d chunks=%d waves=%d", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
-		         pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves);
+		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
+		         pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->wide_fast ? " weights+recheck" : "");
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

@@ -12,7 +12,7 @@
 
 struct FixcaGeom;
 /* waves of the geometry's k_wcol instantiation the device holds at once, 0 if there is no device to ask (fixca_wide.hip) */
-extern "C" int fixca_wide_slots(const struct FixcaGeom *g);
+extern "C" int fixca_wide_slots(const struct FixcaGeom *g, int fast);
 
 struct WidePlan {
 	int oc, th, nstrips, nwaves, nblocks;

@@ -170,6 +170,49 @@ __device__ __forceinline__ double vfilter(const double (&h)[TAPS], double fy)
 	else return __dadd_rn(__dmul_rn(__dsub_rn(1.0, fy), h[0]), __dmul_rn(fy, h[1]));     /* fix-ca.c:891, outer */
 }
 
+__device__ __forceinline__ int tap_index_rt(int c0, int t, int n) { return max(0, min(c0 - 1 + t, n - 1)); }   /* cubic taps, see tap_index */
+/* ---- 16-bit samples, CUBIC: the same results from a quarter of the arithmetic ---------------------
+ * The reference's value of a sample is v = cubicX(cubicY(row 0..3)) on p = s / 65535, then round(clip(v) * 65535)
+ * (fix-ca.c:896-920, 748-761): 38 fp64 operations in a fixed order plus 16 divisions.  In real arithmetic v * 65535 is
+ * x = sum_t wy_t(fy) * sum_i wx_i(fx) * s_ti with the Catmull-Rom weights below, 8 fused multiply-adds on the integer
+ * samples.  The two differ only by rounding errors: every one of the reference's 19 + 19 operations and 16 divisions
+ * rounds a value of magnitude <= 12 (in units of p) by <= 2^-53 relative, the second filter multiplies the first one's
+ * errors by at most sum |w| <= 1.5, so |x_ref - x| <= (230 + 1.5 * 230 + 16) * 12 * 1.2e-16 * 65535 < 6e-9 samples, and
+ * the weight form's own error is below 1e-9 (measured over 6e7 random, extreme-step and nearly flat windows, numpy
+ * against the operation-for-operation form: 9.8e-11).  The rounded sample can differ only when a rounding boundary
+ * k + 0.5 lies between the two values (clipping to [0, 65535] moves both to the same integer): so x is rounded as the
+ * reference rounds, and the rare sample whose fraction is within WIDE_FAST_EPS = 1e-6 of 0.5 (160 x the bound) is
+ * recomputed operation for operation from the source image (exact_cubic_sample, the one-thread-per-pixel kernel's
+ * code).  The planner (plan_wide) keeps the operation-for-operation variant for geometries whose fractions sit on a
+ * coarse dyadic grid (pure shifts by halves or quarters), where such samples are common. */
+#define WIDE_FAST_EPS 1e-6
+__device__ __forceinline__ void cr_weights(double t, double (&w)[4])
+{
+	const double t2 = t * t, t3 = t2 * t;
+	w[0] = 0.5 * (-t3 + 2.0 * t2 - t);
+	w[1] = 0.5 * (3.0 * t3 - 5.0 * t2 + 2.0);
+	w[2] = 0.5 * (-3.0 * t3 + 4.0 * t2 + t);
+	w[3] = 0.5 * (t3 - t2);
+}
+/* one output sample of channel c (0 red, 1 blue) at (x, y), operation for operation (fix-ca.c:1260-1318) */
+template <typename S, int NCH>
+__device__ __forceinline__ S exact_cubic_sample(const S *__restrict__ src, const FixcaGeom &g, int x, int y, int c)
+{
+	typedef Codec<S> C;
+	const size_t pitch = (size_t)g.W * NCH;
+	const double yd = map_dbl(y, g.yc, g.H, g.s[c], g.ys[c]), xd = map_dbl(x, g.xc, g.W, g.s[c], g.xs[c]);
+	const int r0 = (int)floor(yd), c0 = (int)floor(xd);
+	const double fy = __dsub_rn(yd, (double)r0), fx = __dsub_rn(xd, (double)c0);
+	double h[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const S *row = src + (size_t)tap_index_rt(r0, t, g.H) * pitch + 2 * c;
+		h[t] = cr_exact(C::get(row[(size_t)tap_index_rt(c0, 0, g.W) * NCH]), C::get(row[(size_t)tap_index_rt(c0, 1, g.W) * NCH]),
+		                C::get(row[(size_t)tap_index_rt(c0, 2, g.W) * NCH]), C::get(row[(size_t)tap_index_rt(c0, 3, g.W) * NCH]), fx);
+	}
+	return C::put(clip01(cr_exact(h[0], h[1], h[2], h[3], fy)));
+}
+
 /* tap t of the window that starts at integer coordinate c0, clamped as the reference clamps it:
  * cubic  max(c0-1,0), c0, min(c0+1,n-1), min(min(c0+1,n-1)+1,n-1)  (fix-ca.c:1218-1256, 1270-1298)
  * linear c0, (c0 == n-1) ? c0 : c0+1                               (fix-ca.c:1149-1158, 1170-1177)
@@ -197,12 +240,13 @@ __device__ __forceinline__ int tap_index(int c0, int t, int n)
 #else
 #define WIDE_OCC
 #endif
-template <typename S, int NCH, int TAPS, int Q, bool ODDW>
-__global__ __launch_bounds__(64) WIDE_OCC void
-k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
+template <typename S, int NCH, int TAPS, int Q, bool ODDW, bool FAST>
+__device__ __forceinline__ void
+wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, const WidePlan &wp)
 {
 	typedef Codec<S> C;
 	constexpr int T = TAPS, BACK = (T == 4) ? 1 : 0;
+	static_assert(!FAST || (sizeof(S) == 2 && TAPS == 4), "the weight form is for 16-bit samples, CUBIC");
 	constexpr int SB = (int)sizeof(S);
 	constexpr int PB = NCH * SB;                          /* bytes per pixel                       */
 	constexpr int NW = 2 * PB / 4;                        /* dwords per pixel pair                 */
@@ -265,6 +309,7 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	uint32_t wcol[2][2];                                  /* byte offset in a row of the sample (or pair) this lane fetches */
 	int      sel[2][2];                                   /* PAIRWIN: which pixel of the fetched pair is window column 2 * lane + j */
 	double   fx[2][2];
+	double   wx[FAST ? 2 : 1][2][4];                      /* FAST: the horizontal weights of my two columns */
 #pragma unroll
 	for (int c = 0; c < 2; ++c) {
 		/* T == 1 (NONE): the one tap is the nearest source column, scale() of fix-ca.c:799-809 */
@@ -279,6 +324,7 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 				const double xd = map_dbl(xx, g.xc, W, g.s[c], g.xs[c]);
 				c0 = (int)floor(xd);
 				fx[c][j] = __dsub_rn(xd, (double)c0);
+				if constexpr (FAST) cr_weights(fx[c][j], wx[c][j]);
 			}
 			const int b = max(0, min(c0 - BACK - Uw, WIDE_WIN - T));              /* the planner guarantees the range */
 			hb[c][j] = (lds_xp)&xbuf[c * WIDE_WIN] + b;
@@ -323,6 +369,7 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 			} else { s[0] = (S)raw.w[0]; s[1] = (S)raw.w[1]; }
 		} else { s[0] = get_sample<S>(raw.w, 0); s[1] = get_sample<S>(raw.w, 1); }
 		if constexpr (T == 1) { xbuf[c * WIDE_WIN + 2 * lane] = s[0]; xbuf[c * WIDE_WIN + 2 * lane + 1] = s[1]; }
+		else if constexpr (FAST) { xbuf[c * WIDE_WIN + 2 * lane] = (double)s[0]; xbuf[c * WIDE_WIN + 2 * lane + 1] = (double)s[1]; }
 		else { xbuf[c * WIDE_WIN + 2 * lane] = C::get(s[0]); xbuf[c * WIDE_WIN + 2 * lane + 1] = C::get(s[1]); }
 	};
 	/* the horizontal filter of my two columns on the row in hbuf[c].  One wave: its LDS operations complete in order,
@@ -334,7 +381,8 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 				double p[T];
 #pragma unroll
 				for (int t = 0; t < T; ++t) p[t] = hb[c][j][t];
-				out[j] = hfilter<T>(p, fx[c][j]);
+				if constexpr (FAST) out[j] = fma(wx[c][j][3], p[3], fma(wx[c][j][2], p[2], fma(wx[c][j][1], p[1], wx[c][j][0] * p[0])));
+				else out[j] = hfilter<T>(p, fx[c][j]);
 			}
 		}
 	};
@@ -486,15 +534,44 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 					}
 				}
 				y0prev[0] = y0[0]; y0prev[1] = y0[1];
-				double v[2][2];                                /* [channel][pixel] */
+				if constexpr (FAST) {
+					uint32_t redo = 0;                          /* bit 2 * c + j: recompute that sample */
 #pragma unroll
-				for (int c = 0; c < 2; ++c)
+					for (int c = 0; c < 2; ++c) {
+						double wy[4];
+						cr_weights(sfy[k][c], wy);
 #pragma unroll
-					for (int j = 0; j < 2; ++j) v[c][j] = clip_for_put<C::INTEGER>(vfilter<T>(hh[c][j], sfy[k][c]));
+						for (int j = 0; j < 2; ++j) {
+							double xv = fma(wy[3], hh[c][j][3], fma(wy[2], hh[c][j][2], fma(wy[1], hh[c][j][1], wy[0] * hh[c][j][0])));
+							xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
+							const double fr = __builtin_amdgcn_fract(xv);
+							outv[c][j] = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
+							redo |= (__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS ? 1u : 0u) << (2 * c + j);
+						}
+					}
+					if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0) != 0, 0)) {
+						/* a few samples per image: one copy of the recomputation, the flagged samples of a lane in turn */
+						while (redo) {
+							const int q = __builtin_ctz(redo);
+							redo &= redo - 1;
+							const S e = exact_cubic_sample<S, NCH>(src, g, min(x + (q & 1), W - 1), Y0 + min(r, nrows - 1), q >> 1);
 #pragma unroll
-				for (int c = 0; c < 2; ++c)
+							for (int c = 0; c < 2; ++c)
 #pragma unroll
-					for (int j = 0; j < 2; ++j) outv[c][j] = C::put(v[c][j]);
+								for (int j = 0; j < 2; ++j) outv[c][j] = (q == 2 * c + j) ? e : outv[c][j];
+						}
+					}
+				} else {
+					double v[2][2];                            /* [channel][pixel] */
+#pragma unroll
+					for (int c = 0; c < 2; ++c)
+#pragma unroll
+						for (int j = 0; j < 2; ++j) v[c][j] = clip_for_put<C::INTEGER>(vfilter<T>(hh[c][j], sfy[k][c]));
+#pragma unroll
+					for (int c = 0; c < 2; ++c)
+#pragma unroll
+						for (int j = 0; j < 2; ++j) outv[c][j] = C::put(v[c][j]);
+				}
 			}
 			/* green and alpha are copied (fix-ca.c:1098), red and blue replaced.
 			 * The row offset is added into the per-lane offset and the stores' scalar offset is the constant 0.  With the
@@ -579,13 +656,38 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 	}
 }
 
-/* the instantiation a geometry runs: sample type x (interpolation, samples per pixel, odd width) */
+template <typename S, int NCH, int TAPS, int Q, bool ODDW>
+__global__ __launch_bounds__(64) WIDE_OCC void
+k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
+{
+	wcol_tile<S, NCH, TAPS, Q, ODDW, false>(src, dst, g, wp);
+}
+/* The weight form keeps 16 weights per lane on top of the window and sits at 194 registers; held to 168 (3 waves per
+ * SIMD) it spills 9-15 dwords and is still faster: 106 vs 113 us on 6000x4000 RGBA u16. */
+template <typename S, int NCH, int Q, bool ODDW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void
+k_wcol_weights(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
+{
+	wcol_tile<S, NCH, 4, Q, ODDW, true>(src, dst, g, wp);
+}
+
+/* the instantiation a geometry runs: sample type x (interpolation, samples per pixel, odd width); `fast`: the weight
+ * form with exact recomputation (16-bit samples, CUBIC, when the planner allows it) */
 template <typename S>
-const void *wcol_kernel(int sel)
+const void *wcol_kernel(int sel, bool fast)
 {
 	/* queue slots: 3 where the registers allow it with 3 waves per SIMD (RGBA u16: 162-164), else 2 (measured equal
 	 * within 3 % on RGBA u16; a third slot would push RGBA float and RGB u16 past 168 registers) */
 	constexpr int Q4 = sizeof(S) == 2 ? WIDE_SLOTS : WIDE_SLOTS - 1, Q3 = WIDE_SLOTS - 1;
+	if constexpr (sizeof(S) == 2) {
+		if (fast) switch (sel) {
+		case 11: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, 2, true>);
+		case 10: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, 2, false>);
+		case 9:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, 2, true>);
+		case 8:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, 2, false>);
+		default: break;
+		}
+	}
 	switch (sel) {
 	case 11: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, true>);
 	case 10: return reinterpret_cast<const void *>(&k_wcol<S, 4, 4, Q4, false>);
@@ -603,14 +705,14 @@ const void *wcol_kernel(int sel)
 }
 int wcol_type_index(int bpc) { return bpc == 2 ? 0 : bpc == 4 ? 1 : bpc == -4 ? 2 : bpc == -8 ? 3 : -1; }
 int wcol_selector(const FixcaGeom *g) { return 4 * g->interp + (g->nch == 4 ? 2 : 0) + (g->W & 1); }     /* interp 0, 1, 2 */
-const void *wcol_kernel_for(const FixcaGeom *g)
+const void *wcol_kernel_for(const FixcaGeom *g, bool fast)
 {
 	const int sel = wcol_selector(g);
 	switch (g->bpc) {
-	case 2:  return wcol_kernel<uint16_t>(sel);
-	case 4:  return wcol_kernel<uint32_t>(sel);
-	case -4: return wcol_kernel<float>(sel);
-	case -8: return wcol_kernel<double>(sel);
+	case 2:  return wcol_kernel<uint16_t>(sel, fast);
+	case 4:  return wcol_kernel<uint32_t>(sel, fast);
+	case -4: return wcol_kernel<float>(sel, fast);
+	case -8: return wcol_kernel<double>(sel, fast);
 	default: return nullptr;
 	}
 }
@@ -623,10 +725,11 @@ const void *wcol_kernel_for(const FixcaGeom *g)
  * the same work, so the launch is fastest when all tiles are resident together and every SIMD has the same number.
  */
 extern "C" int
-fixca_wide_slots(const FixcaGeom *g)
+fixca_wide_slots(const FixcaGeom *g, int fast)
 {
 	static std::mutex mu;
-	static int cached[4][12];                              /* 0 = not asked yet, -1 = cannot be asked */
+	static int cached_all[2][4][12];
+	int (&cached)[4][12] = cached_all[fast ? 1 : 0];                              /* 0 = not asked yet, -1 = cannot be asked */
 	const int ti = wcol_type_index(g->bpc);
 	if (ti < 0 || g->interp < 0 || g->interp > 2) return 0;
 	const int sel = wcol_selector(g);
@@ -635,7 +738,7 @@ fixca_wide_slots(const FixcaGeom *g)
 		int per_cu = 0, dev = 0, cus = 0;
 		if (hipGetDevice(&dev) == hipSuccess &&
 		    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-		    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wcol_kernel_for(g), 64, 0) == hipSuccess && per_cu > 0 && cus > 0)
+		    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wcol_kernel_for(g, fast != 0), 64, 0) == hipSuccess && per_cu > 0 && cus > 0)
 			cached[ti][sel] = per_cu * cus;
 		else {
 			(void)hipGetLastError();
@@ -650,7 +753,7 @@ fixca_launch_wide(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 {
 	if (g->y2 <= g->y1) return hipSuccess;
 	if (g->interp < 0 || g->interp > 2) return hipErrorInvalidValue;
-	const void *fn = wcol_kernel_for(g);
+	const void *fn = wcol_kernel_for(g, pl->wide_fast != 0);
 	if (!fn) return hipErrorInvalidValue;
 	WidePlan wp;
 	wp.oc = pl->oc; wp.th = pl->th; wp.nstrips = pl->nstrips; wp.nwaves = pl->nwaves; wp.nblocks = pl->nblocks;

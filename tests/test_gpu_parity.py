@@ -365,6 +365,37 @@ def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
     assert seen <= {1, 7}
 
 
+@pytest.mark.parametrize("nch", [3, 4])
+def test_wide_weights_kernel_recomputes_boundary_samples(torch_cuda, nch, monkeypatch):
+    """16-bit CUBIC runs the weight form of the filter and recomputes, operation for operation, the samples whose value
+    is within 1e-6 of a rounding boundary (fixca_wide.hip).  Pure shifts by halves and quarters make such samples
+    common (every 16th with fx = 1/2, fy = 0): the planner then keeps the operation-for-operation variant, and with
+    the weight form forced the results must still be the oracle's, bit for bit."""
+    torch = torch_cuda
+    w, h, bpc, sb = 700, 300, 2, 2
+    img = _wide_image(np.uint16, w, h, nch, 4242 + nch)
+    src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+    cases = [dict(lens_x=350, lens_y=150, x_blue=0.5, y_red=-0.5), dict(lens_x=350, lens_y=150, x_blue=0.25, y_blue=0.5, x_red=-1.5),
+             dict(lens_x=350, lens_y=150, blue=350.0 * 1e-13, red=0.0, x_blue=0.5, x_red=0.5),        # a scale a hair off 1: near-boundary, not on it
+             dict(lens_x=10, lens_y=20, blue=2.0, red=-2.0)]
+    for kw in cases:
+        p = fixca.make_params(interpolation=2, **kw)
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
+        for force in ("", "FIXCA_WCOL_WEIGHTS", "FIXCA_WCOL_REF"):
+            for name in ("FIXCA_WCOL_WEIGHTS", "FIXCA_WCOL_REF"):
+                monkeypatch.delenv(name, raising=False)
+            if force:
+                monkeypatch.setenv(force, "1")
+            kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
+            assert kid == 7
+            weights = "weights+recheck" in desc
+            assert weights == (force == "FIXCA_WCOL_WEIGHTS" or (force == "" and kw.get("blue", 0.0) == 2.0)), (desc, kw, force)
+            dst = torch.zeros_like(src)
+            fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+            torch.cuda.synchronize()
+            assert dst.cpu().numpy().tobytes() == ref.view(np.uint8).tobytes(), (desc, kw)
+
+
 @pytest.mark.parametrize("idx", range(int(os.environ.get("FIXCA_FUZZ_N", "32"))))
 def test_fuzz_wide_any_width(torch_cuda, idx):
     """the wide sample types on images of ANY width from 2 pixels up (odd widths, RGB rows that do not end on a
