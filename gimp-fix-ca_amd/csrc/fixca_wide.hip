@@ -664,8 +664,11 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 }
 /* The weight form keeps 16 weights per lane on top of the window and sits at 194 registers; held to 168 (3 waves per
  * SIMD) it spills 9-15 dwords and is still faster: 106 vs 113 us on 6000x4000 RGBA u16. */
+#ifndef WIDE_WEIGHTS_WAVES
+#define WIDE_WEIGHTS_WAVES 3
+#endif
 template <typename S, int NCH, int Q, bool ODDW>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WIDE_WEIGHTS_WAVES))) void
 k_wcol_weights(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 {
 	wcol_tile<S, NCH, 4, Q, ODDW, true>(src, dst, g, wp);
