@@ -87,3 +87,17 @@ def test_reciprocal_division_is_exact(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.split() == ["u8", "0", "u16", "0", "u32", "0"], out.stdout
+
+
+def test_weight_form_error_bound(tmp_path):
+    """k_wcol's 16-bit CUBIC weight form (fixca_wide.hip): over 12 million windows (random, extreme steps, nearly
+    flat, ramps; random and coarse dyadic fractions) the weight form stays within 1e-8 samples of the reference's
+    operation order (the kernel rechecks within 1e-6 of a rounding boundary), and no unflagged sample rounds
+    differently"""
+    import subprocess
+    exe = tmp_path / "weightbound"
+    src = os.path.join(os.path.dirname(__file__), "c", "weightbound.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    worst, unflagged, flagged = out.stdout.split()
+    assert out.returncode == 0 and float(worst) < 1e-8 and int(unflagged) == 0 and int(flagged) > 0, out.stdout

@@ -1,0 +1,42 @@
+"""GPU box: soak of k_wcol's 16-bit CUBIC weight form against the one-thread-per-pixel fp64 kernel: N random parameter
+sets (lateral amounts up to the plug-in's +-30, lens anywhere, some with directional shifts) on 6000x4000 RGBA / RGB u16
+images of three kinds (noise, smooth ramps, ramps with a little noise).  Every sample must be identical.
+usage: wide_soak.py [N]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gimp-fix-ca_amd"))
+import numpy as np, torch, fixca
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+W, H = 6000, 4000
+rng = np.random.default_rng(0x50AC)
+total = bad = weights_runs = 0
+for it in range(N):
+    nch = 3 if it % 4 == 3 else 4
+    kind = it % 3
+    if kind == 0:
+        raw = torch.empty((H, W, nch * 2), dtype=torch.uint8, device="cuda"); fixca.noise_fill(raw, 0x50AC0000 + it)
+        img = raw.view(torch.int16).reshape(H, W, nch)
+    else:
+        yy = torch.arange(H, device="cuda", dtype=torch.float64)[:, None, None]; xx = torch.arange(W, device="cuda", dtype=torch.float64)[None, :, None]
+        cc = torch.arange(nch, device="cuda", dtype=torch.float64)[None, None, :]
+        v = (xx * (5.0 + it) + yy * (3.0 + 0.5 * it) + cc * 4099.0 + (xx * yy) / 977.0) % 65536.0
+        if kind == 2:
+            v = (v + torch.randint(0, 5, (H, W, nch), device="cuda").to(torch.float64)) % 65536.0
+        img = v.to(torch.int32).to(torch.int16)       # bit pattern of the u16 value
+        raw = img.contiguous().view(torch.uint8).reshape(H, W, nch * 2)
+    mag = [0.5, 2.0, 8.0, 30.0][it % 4]
+    kw = dict(blue=float(rng.uniform(-mag, mag)), red=float(rng.uniform(-mag, mag)), lens_x=float(rng.integers(-1, W + 1)), lens_y=float(rng.integers(-1, H + 1)))
+    if it % 5 == 0:
+        kw.update(x_blue=float(rng.uniform(-mag, mag)), y_red=float(rng.uniform(-mag, mag)))
+    p = fixca.make_params(interpolation=2, **kw)
+    desc = fixca.plan(W, H, nch * 2, 2, p)[1]
+    weights_runs += "weights+recheck" in desc
+    a = torch.zeros_like(raw); b = torch.zeros_like(raw)
+    fixca.fix_ca_region(raw, a, W, H, nch * 2, 2, p, 0, W, 0, H, True, fixca.KERNEL_AUTO)
+    fixca.fix_ca_region(raw, b, W, H, nch * 2, 2, p, 0, W, 0, H, True, fixca.KERNEL_EXACT)
+    torch.cuda.synchronize()
+    d = int((a.view(torch.int16) != b.view(torch.int16)).sum())
+    total += H * W * 2; bad += d
+    print("%2d nch=%d kind=%d %-60s differing %d  [%s]" % (it, nch, kind, str({k: round(v, 3) for k, v in kw.items()})[:60], d, desc[-40:]), flush=True)
+print("red/blue samples compared: %d, differing: %d, runs on the weight form: %d of %d" % (total, bad, weights_runs, N))
+sys.exit(1 if bad else 0)
