@@ -329,7 +329,12 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 			const int b = max(0, min(c0 - BACK - Uw, WIDE_WIN - T));              /* the planner guarantees the range */
 			hb[c][j] = (lds_xp)&xbuf[c * WIDE_WIN] + b;
 		}
-		const int col0 = max(0, min(Uw + 2 * lane, W - 1)), col1 = max(0, min(Uw + 2 * lane + 1, W - 1));
+		/* which two window columns this lane fetches: a pair (2 lane, 2 lane + 1) where the pair is one 12/16-byte load
+		 * (16-bit samples); lane and lane + 64 for the sample loads of the wider types, so that a load instruction's 64
+		 * samples lie in 64 consecutive pixels (half the cache lines of the pair order) */
+		constexpr bool SPLIT = !PAIRWIN;
+		const int wi0 = SPLIT ? lane : 2 * lane, wi1 = SPLIT ? lane + 64 : 2 * lane + 1;
+		const int col0 = max(0, min(Uw + wi0, W - 1)), col1 = max(0, min(Uw + wi1, W - 1));
 		if constexpr (PAIRWIN && al4) {
 			const int bp = max(0, min(Uw + 2 * lane, W - 2));
 			wcol[c][0] = wcol[c][1] = (uint32_t)bp * PB;
@@ -368,9 +373,10 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				for (int i = 0; i < RW; ++i) asm volatile("" :: "v"(raw.w[i]));
 			} else { s[0] = (S)raw.w[0]; s[1] = (S)raw.w[1]; }
 		} else { s[0] = get_sample<S>(raw.w, 0); s[1] = get_sample<S>(raw.w, 1); }
-		if constexpr (T == 1) { xbuf[c * WIDE_WIN + 2 * lane] = s[0]; xbuf[c * WIDE_WIN + 2 * lane + 1] = s[1]; }
-		else if constexpr (FAST) { xbuf[c * WIDE_WIN + 2 * lane] = (double)s[0]; xbuf[c * WIDE_WIN + 2 * lane + 1] = (double)s[1]; }
-		else { xbuf[c * WIDE_WIN + 2 * lane] = C::get(s[0]); xbuf[c * WIDE_WIN + 2 * lane + 1] = C::get(s[1]); }
+		const int i0 = PAIRWIN ? 2 * lane : lane, i1 = PAIRWIN ? 2 * lane + 1 : lane + 64;      /* the window columns fetched, see wcol */
+		if constexpr (T == 1) { xbuf[c * WIDE_WIN + i0] = s[0]; xbuf[c * WIDE_WIN + i1] = s[1]; }
+		else if constexpr (FAST) { xbuf[c * WIDE_WIN + i0] = (double)s[0]; xbuf[c * WIDE_WIN + i1] = (double)s[1]; }
+		else { xbuf[c * WIDE_WIN + i0] = C::get(s[0]); xbuf[c * WIDE_WIN + i1] = C::get(s[1]); }
 	};
 	/* the horizontal filter of my two columns on the row in hbuf[c].  One wave: its LDS operations complete in order,
 	 * the reads see the writes of convert() */

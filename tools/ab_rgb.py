@@ -25,6 +25,7 @@ SETS = {
             V("RDEPTH=10 ring=20 th=25", "ab_rd10", {"FIXCA_RING": "20", "FIXCA_TH": "25"}), V("RDEPTH=4 th=25", "ab_rd4", {"FIXCA_TH": "25"}),
             V("RDEPTH=4 ring=12 th=25", "ab_rd4", {"FIXCA_RING": "12", "FIXCA_TH": "25"}), V("ring=14 th=25", env={"FIXCA_RING": "14", "FIXCA_TH": "25"}),
             V("ring=12 th=21", env={"FIXCA_RING": "12", "FIXCA_TH": "21"}), V("th=17", env={"FIXCA_TH": "17"}), V("th=21", env={"FIXCA_TH": "21"}), V("HEAD (again)")],
+ "nrb": [V("HEAD"), V("NRB=8", "ab_nrb8"), V("NRB=6", "ab_nrb6"), V("NRB=2", "ab_nrb2"), V("NRB=2 ring=14", "ab_nrb2", {"FIXCA_RING": "14"}), V("NRB=8 ring=20", "ab_nrb8", {"FIXCA_RING": "20"}), V("HEAD (again)")],
  "knobs": [V("HEAD"), V("th=21", env={"FIXCA_TH": "21"}), V("th=25", env={"FIXCA_TH": "25"}), V("th=29", env={"FIXCA_TH": "29"}), V("th=41", env={"FIXCA_TH": "41"}),
            V("th=57", env={"FIXCA_TH": "57"}), V("ring=14", env={"FIXCA_RING": "14"}), V("ring=18", env={"FIXCA_RING": "18"}), V("ring=20", env={"FIXCA_RING": "20"}),
            V("ring=24", env={"FIXCA_RING": "24"}), V("ring=20 th=25", env={"FIXCA_RING": "20", "FIXCA_TH": "25"}), V("oc=248", env={"FIXCA_OC": "248"}), V("oc=224", env={"FIXCA_OC": "224"}),
