@@ -20,6 +20,7 @@ HEAD = fixca.LIB_PATH
 def V(name, lib=None, env=None, per=64):
     return (name, HEAD if lib is None else os.path.join(BIN, lib, "libfixca_hip.so"), env or {}, per)
 SETS = {
+ "one": [V("HEAD")],
  "structure": [V("HEAD, 64 per launch"), V("HEAD, 32 per launch", per=32), V("HEAD, 16 per launch", per=16),
                V("HEAD, 128 per launch (ROLL_BATCH_MAX=128 build)", "ab_b128", per=128),
                V("64-byte aligned 272-column window, DPP kept", "ab_al64"), V("nt ring loads", "ab_ldnt"),
