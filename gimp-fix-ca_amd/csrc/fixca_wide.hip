@@ -1,12 +1,12 @@
 /*
  * fixca_wide.hip — the row-rolling kernel for the sample types beyond 8 bits (SURVEY §8f row 1:
  * get_pixel / set_pixel for u16, u32, float and double samples, fix-ca.c:713-774; color_size codes
- * 2, 4, -4, -8), LINEAR and CUBIC.
+ * 2, 4, -4, -8): LINEAR and CUBIC on all of them, NONE on the 16-bit ones.  Bit-identical to the CPU oracle.
  *
- * The arithmetic is the reference's, in fp64, operation for operation (the same helpers as the
- * one-thread-per-pixel kernel k_wide, which stays as the checker and the fallback): the results
- * are bit-identical to the CPU oracle.  What changes is how often each piece is computed.  The
- * map is separable (x' depends on the column only, y' on the row only), so
+ * LINEAR / CUBIC: the arithmetic is the reference's, in fp64, operation for operation (the same helpers as
+ * the one-thread-per-pixel kernel k_wide, which stays as the checker and the fallback).  What changes is
+ * how often each piece is computed.  The map is separable (x' depends on the column only, y' on the row
+ * only), so
  *
  *   - get_pixel runs ONCE per source sample and row visit, not once per tap: a lane converts the
  *     samples of its own two window columns and the wave shares the doubles through 2 KB of LDS
@@ -19,11 +19,19 @@
  *     value of an expression is not a change of rounding: every operation still sees the operands
  *     the reference's would.
  *
- * One wave per tile of `oc` = 120 output columns x `th` rows, two pixels per lane (a 16-byte load
- * and store per lane for RGBA u16).  Each channel has its own 128-column source window, so any
- * shift fits; only the drift of the tap offset over a strip is limited (the planner checks it and
- * falls back to k_wide).  Global memory is read with plain loads: a source row is visited up to
- * three times (as red row, blue row, identity row), a few rows apart; the repeats are L1/L2 hits.
+ * 16-bit CUBIC has a second variant (k_wcol_weights): the two filters as weighted sums, with every sample
+ * whose value comes within 1e-6 of a rounding boundary recomputed the reference's way (see cr_weights below
+ * for the bound that makes this exact).  NONE on 16-bit samples is the same kernel with one tap and no
+ * conversion (the samples are copied through LDS as they are).
+ *
+ * One wave per tile of `oc` = 120 output columns x `th` rows, two pixels per lane.  Each channel has its
+ * own 128-column source window, so any shift fits; only the drift of the tap offset over a strip is limited
+ * (the planner checks it and falls back to k_wide).  Memory is read and written with buffer instructions
+ * and no branch around them: an output row's loads (the one source row each channel's window gains, and the
+ * row's own pixels for green and alpha) sit in a register queue 1-2 rows ahead with counted waits; pixels of
+ * 12 bytes and more move as 16-byte units in lane order (full-sector stores), the results reaching the
+ * storing lane through LDS.  All tiles of a launch are resident at once (the planner sizes them to the
+ * occupancy the runtime reports): the kernel is bound by instruction issue, not by memory.
  */
 #include "fixca_device.h"
 #include "fixca_wide.h"
