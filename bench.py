@@ -46,6 +46,9 @@ CONFIGS = [
     dict(name="RGB8 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=1, params=PARAMS),
     dict(name="RGBA u16 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=PARAMS, images=8),
     dict(name="RGBA float cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=PARAMS, images=8),
+    dict(name="RGBA u16 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=1), images=8),
+    dict(name="RGBA u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=0), images=8),
+    dict(name="RGBA double cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=PARAMS, images=4),
 ]
 
 
