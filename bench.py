@@ -133,7 +133,7 @@ def run_configs(torch, fixca, dev, per_launch):
     for cfg in CONFIGS:
         w, h, c, bpc = cfg["w"], cfg["h"], cfg["c"], cfg["bpc"]
         bytes_pp = c * sample_bytes(bpc)
-        n = cfg.get("images", min(per_launch, 64 if cfg["w"] * cfg["h"] <= 6000 * 4000 else 32))
+        n = cfg.get("images", min(per_launch, 128 if cfg["w"] * cfg["h"] <= 6000 * 4000 else 32))     # 8-bit configs: as many per launch as the headline
         p = fixca.make_params(**cfg["params"])
         entry = {"name": cfg["name"], "width": w, "height": h, "bytes_per_pixel": bytes_pp, "bpc": bpc}
         try:
@@ -142,7 +142,7 @@ def run_configs(torch, fixca, dev, per_launch):
             srcs = [raw[i] for i in range(n)]
             dstt = torch.empty_like(raw)
             dsts = [dstt[i] for i in range(n)]
-            reps = max(4, 1024 // n)             # >= 32 launches: short runs read a few percent slow (clock ramp)
+            reps = max(4, 1024 // n)             # >= 1024 image passes: short runs read a few percent slow (clock ramp)
             us = time_batch(torch, fixca, srcs, dsts, w, h, bytes_pp, bpc, p, per_launch, reps)
             algo = 2.0 * w * h * bytes_pp
             # sanity next to the number: the fast path against the fp64 kernel on image 0 (integer formats: <= 1 LSB)
