@@ -1,6 +1,6 @@
 """GPU box: soak of k_wcol's 16-bit CUBIC weight form against the one-thread-per-pixel fp64 kernel: N random parameter
 sets (lateral amounts up to the plug-in's +-30, lens anywhere, some with directional shifts) on 6000x4000 RGBA / RGB u16
-images of three kinds (noise, smooth ramps, ramps with a little noise).  Every sample must be identical.
+images of four kinds (noise, smooth ramps, ramps with a little noise, random 0 / 65535 steps).  Every sample must be identical.
 usage: wide_soak.py [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,8 +12,11 @@ rng = np.random.default_rng(0x50AC)
 total = bad = weights_runs = 0
 for it in range(N):
     nch = 3 if it % 4 == 3 else 4
-    kind = it % 3
-    if kind == 0:
+    kind = it % 4 if N > 12 else it % 3
+    if kind == 3:
+        img = (torch.randint(0, 2, (H, W, nch), device="cuda", dtype=torch.int32) * 65535).to(torch.int16)      # extreme steps
+        raw = img.contiguous().view(torch.uint8).reshape(H, W, nch * 2)
+    elif kind == 0:
         raw = torch.empty((H, W, nch * 2), dtype=torch.uint8, device="cuda"); fixca.noise_fill(raw, 0x50AC0000 + it)
         img = raw.view(torch.int16).reshape(H, W, nch)
     else:
