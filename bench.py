@@ -12,6 +12,12 @@ no cache level can serve a repeat.  N > 1 (one rank per GPU, torch.distributed.r
 broadcasts the 80-byte parameter block over RCCL, no pixel crosses GPUs, the total work is fixed
 (strong scaling).  Prints ONE JSON line on rank 0.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: the
+parent (which never touches the GPU, not even through an import) runs `python -m
+torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`
+as a child process, relays rank 0's JSON line and exits with the child's code.  Launched under
+torch.distributed.run by somebody else (WORLD_SIZE set) it is a rank.
+
 Untimed extras on rank 0 at N = 1 (skipped with --no-extras): `single_image_launch` (one image per
 launch, what fix_ca_region does for the plug-in), `configs` (every BASELINE configuration through the
 same timing method), the on-box copy yardstick, the host entry (PCIe inclusive), `cold_call_ms`
@@ -50,6 +56,28 @@ CONFIGS = [
     dict(name="RGBA u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=0), images=8),
     dict(name="RGBA double cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=PARAMS, images=4),
 ]
+
+
+def oracle_image0(params_dict, threads=None):
+    """The CPU oracle's result for image 0 of the batch (noise(SEED0)): the checker of the bench line's parity.
+    The row-band OpenMP build computes the same bytes as the single thread (tests/test_oracle_golden.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import pyoracle
+    from fixca import synth
+    img = synth.noise_image(SEED0, W, H, C)
+    dst = np.empty_like(img)
+    nthr = threads or max(1, min(len(os.sched_getaffinity(0)), 64))
+    pyoracle.region(img, pyoracle.make_params(**params_dict), dst=dst, threads=nthr)
+    return dst
+
+
+def oracle_diff(np, got, ref):
+    """{max_abs_diff, differing} of a GPU result against the oracle's (uint8 images)"""
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    return {"image": 0, "max_abs_diff": int(d.max()), "differing": int(np.count_nonzero(d)), "samples": int(d.size),
+            "green_alpha_equal": bool(np.array_equal(got[..., 1::2], ref[..., 1::2])),
+            "bar": "<= 1 LSB on red/blue (north_star), green/alpha exact"}
 
 
 def cpu_baseline(params_dict):
@@ -92,6 +120,21 @@ def cpu_baseline(params_dict):
 
 def sample_bytes(bpc):
     return abs(bpc)
+
+
+KID_ROLL = 6                     # fixca_plan_describe's id of the row-rolling kernel (include/fixca_hip.h)
+
+
+def kernel_name(kid, plan_text):
+    """the device function a plan runs, from the planner's own description"""
+    words = plan_text.split()
+    if kid == KID_ROLL:
+        taps = {"none": 1, "linear": 2, "cubic": 4}[words[1]]
+        ring = int([w for w in words if w.startswith("ring=")][0][5:])
+        rgb = "bpp=3" in words
+        return "k_roll%s<%d,%s>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false")
+    return {"exact-fp64": "k_exact/k_wide", "fast-none": "k_none", "fast-interp": "k_interp", "scan": "k_scan", "scanw": "k_scanw",
+            "wide-roll-fp64": "k_wcol", "move-none": "k_move"}.get(words[0], words[0])
 
 
 def make_images(torch, fixca, n, h, w, c, bpc, seed0, dev):
@@ -160,7 +203,9 @@ def run_configs(torch, fixca, dev, per_launch):
             else:
                 dt = torch.float32 if bpc == -4 else torch.float64
                 md = float((dsts[0].view(dt).to(torch.float64) - exact.view(dt).to(torch.float64)).abs().max())
-            entry.update({"kernel_plan": desc, "images_per_launch": min(n, per_launch), "launches_timed": reps * ((n + per_launch - 1) // per_launch),
+            # the row-rolling kernel (plan id 6) takes up to per_launch images in one launch; every other kernel is one launch per image
+            ipl = min(n, per_launch) if kid == KID_ROLL else 1
+            entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc), "images_per_launch": ipl, "launches_timed": reps * ((n + ipl - 1) // ipl),
                           "us_per_image": round(us, 2), "GBs": round(algo / us / 1e3, 1),
                           "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4), "mpix_s": round(w * h / us, 1),
                           "max_abs_diff_vs_fp64_kernel": md})
@@ -204,7 +249,7 @@ def cold_call(torch, hsrc):
             "file read, fixca_region_host, file write, exit; best of 2"}, out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -216,29 +261,75 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras that launch other kernels or single images; tools/profile.sh uses "
                          "it so that rocprof's per-kernel average is over the timed launches only")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) with no rendezvous in the environment: start the N ranks.
+    The parent has imported nothing that initialises HIP (no torch, no fixca) and starts
+    torch.distributed.run as a CHILD process (never exec: SURVEY/driver rule for this pool), relays
+    rank 0's JSON line on stdout and everything else on stderr, and returns the child's exit code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line_out = None
+    for line in child.stdout:
+        t = line.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line_out = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = child.wait()
+    if line_out:
+        print(line_out, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        # a driver that asks for N GPUs must not get a 1-GPU number with exit code 0
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (got %d): launch N > 1 with "
-                         "python -m torch.distributed.run --nproc-per-node N" % (args.gpus, args.gpus, world))
+        # a driver that asks for N GPUs must not get a number for another N with exit code 0
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` (it starts its own ranks) or "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N" % (args.gpus, world))
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     import fixca                      # raises if libfixca_hip.so is missing: no fallback
     from fixca import dist as fdist
+    from fixca import synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible")
     # FIXCA_BENCH_REHEARSE=1: several ranks share the one GPU of a test box and talk over gloo, to
-    # rehearse the N > 1 control flow; the real run is one rank per GPU over RCCL
+    # rehearse the N > 1 control flow (tests/test_gpu_parity.py::test_bench_two_ranks_rehearsal);
+    # the real run is one rank per GPU over RCCL
     rehearse = os.environ.get("FIXCA_BENCH_REHEARSE") == "1"
-    local = local % torch.cuda.device_count() if rehearse else local
+    ndev = torch.cuda.device_count()
+    if not rehearse and world > ndev:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (FIXCA_BENCH_REHEARSE=1 shares one GPU between ranks)" % (world, ndev))
+    local = local % ndev if rehearse else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if rehearse else dev          # where the few bytes of the collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -247,10 +338,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     # rank 0 owns the parameters; everyone else receives them over RCCL
-    params = fdist.broadcast_params(fixca.make_params(**PARAMS) if rank == 0 else None, src=0, device=dev)
+    params = fdist.broadcast_params(fixca.make_params(**PARAMS) if rank == 0 else None, src=0, device=cdev)
     kid, plan_text = fixca.plan(W, H, C, 1, params, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)   # what fix_ca_batch will run
 
     G = args.batch * world if args.batch else args.global_batch
+    if G < world:
+        raise SystemExit("bench.py: a batch of %d images cannot give every one of %d ranks an image" % (G, world))
     own = fdist.shard_indices(G, rank, world)               # image i -> rank i mod N
     n_own = len(own)
     P = max(1, min(args.per_launch, 128))
@@ -295,7 +388,7 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
 
     if world > 1:
-        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = t.tolist()
 
@@ -306,7 +399,10 @@ def main():
     exact = torch.empty_like(srcs[0])
     worst, differing = 0, 0
     checked = sorted(set([0, min(31, n_own - 1), min(32, n_own - 1), n_own - 1]))
+    seeds_ok = True
     for j in checked:
+        # the image this rank holds at slot j IS image own[j] of the batch: its first bytes are noise(SEED0 + own[j])'s
+        seeds_ok = seeds_ok and bool(np.array_equal(srcs[j].reshape(-1)[:64].cpu().numpy(), synth.noise_bytes(SEED0 + own[j], 64)))
         fixca.fix_ca_region(srcs[j], exact, W, H, C, 1, params, 0, W, 0, H, True, fixca.KERNEL_EXACT)
         torch.cuda.synchronize()
         diff = (dsts[j].to(torch.int16) - exact.to(torch.int16)).abs()
@@ -315,14 +411,26 @@ def main():
         ok = ok and torch.equal(dsts[j][..., 1], srcs[j][..., 1]) and torch.equal(dsts[j][..., 3], srcs[j][..., 3])
     checks["green_alpha_copied_exactly"] = bool(ok)
     checks["within_1_lsb_of_fp64_kernel"] = worst <= 1
-    ok = ok and worst <= 1
+    checks["held_images_are_the_owned_ones"] = seeds_ok
+    ok = ok and worst <= 1 and seeds_ok
     del exact, diff
-    ok = fdist.all_ranks_ok(ok, device=dev if world > 1 and not rehearse else "cpu")
+    # the oracle's verdict on the timed batch itself: image 0 (rank 0 owns it) against oracle/ on the host,
+    # taken before any extra touches dsts
+    if rank == 0 and not args.no_cpu_baseline:
+        ref0 = oracle_image0(PARAMS)
+        batch0 = dsts[0].cpu().numpy()
+        extra["parity_vs_oracle"] = oracle_diff(np, batch0, ref0)
+        checks["within_1_lsb_of_cpu_oracle"] = extra["parity_vs_oracle"]["max_abs_diff"] <= 1 and extra["parity_vs_oracle"]["green_alpha_equal"]
+        ok = ok and checks["within_1_lsb_of_cpu_oracle"]
+    owned = [own]
+    if world > 1:
+        owned = [None] * world
+        dist.all_gather_object(owned, own)
+    ok = fdist.all_ranks_ok(ok, device=cdev)
     if rank == 0:
         extra["parity_vs_fp64_kernel"] = {"images_checked": [own[j] for j in checked], "max_abs_diff": worst,
                                           "max_differing_samples_per_image": differing, "samples_per_image": W * H * C}
         if world == 1 and not args.no_extras:
-            import numpy as np
             # (1) one image per launch: what fix_ca_region does for the plug-in (8 rotated pairs, 200 launches)
             nrot = min(8, n_own)
             one_ms = fixca.time_launches(srcs[:nrot], dsts[:nrot], 200, W, H, C, 1, params)
@@ -332,6 +440,9 @@ def main():
                                             "kernel_plan": plan1}
             # (2) the on-box copy yardstick over the same buffers (it overwrites dsts: keep what is compared later)
             batch0 = dsts[0].cpu().numpy()
+            if "parity_vs_oracle" in extra:              # one image per launch against the oracle too
+                extra["single_image_launch"]["parity_vs_oracle"] = oracle_diff(np, batch0, ref0)
+                ok = ok and extra["single_image_launch"]["parity_vs_oracle"]["max_abs_diff"] <= 1
             copy_ms = fixca.time_copy(srcs[:32], dsts[:32], 320, W * H * C)
             extra["copy_kernel_GBs"] = round(2 * W * H * C / (copy_ms * 1e-3) / 1e9, 1)
             # (3) the host entry, PCIe inclusive (never the bench value)
@@ -386,10 +497,13 @@ def main():
                        "global_batch": G, "images_per_gpu_per_step": n_own, "images_per_launch": imgs_per_launch,
                        "launches_per_step": launches_per_step,
                        "parallelism": "image i -> rank i mod %d, params broadcast from rank 0, no pixel traffic" % world,
+                       "images_by_rank": [o if len(o) <= 16 else o[:4] + ["..."] + o[-2:] for o in owned],
+                       "transport": "gloo, ranks sharing GPU 0 (FIXCA_BENCH_REHEARSE: control-flow rehearsal, not a measurement)" if rehearse
+                                    else ("rccl" if world > 1 else "none"),
                        "kernel_plan": plan_text},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_roll<4,true>", "kernel_us": round(kernel_ms * 1e3, 2),
+                         "kernel": kernel_name(kid, plan_text), "kernel_us": round(kernel_ms * 1e3, 2),
                          "launches_timed": args.steps * launches_per_step,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "images_per_launch": imgs_per_launch, "us_per_image": round(kernel_ms * 1e3 / imgs_per_launch, 2)},

@@ -34,9 +34,8 @@ struct FixcaPlan {
 	int nwaves;         /* nstrips * nchunks                                 */
 	int nblocks;        /* workgroups, padded to a multiple of 8 (256 threads
 	                       for kernels 2,3; one 64-thread wave for kernel 4)  */
-	int ring;           /* kernels 4,5: source rows in the LDS ring            */
-	int ablate;         /* timing experiments only (FIXCA_ABLATE): 1 = skip the filter
-	                       arithmetic, 2 = skip the counted waits; results are wrong */
+	int ring;           /* kernels 4, 6, 8: source rows in the LDS ring         */
+	int reserved_;      /* (was an experiment switch; kept so the struct's layout does not move) */
 	int wide_fast;      /* kernel 7, 16-bit samples, CUBIC: the weight form with exact recomputation of the
 	                       samples near a rounding boundary (fixca_wide.hip); 0 = operation for operation */
 };
@@ -45,7 +44,7 @@ struct FixcaPlan {
 #define FIXCA_K_NONE    2
 #define FIXCA_K_INTERP  3
 #define FIXCA_K_SCAN    4
-#define FIXCA_K_SCANW   5   /* scan with the ring shared by the 4 waves of a workgroup */
+/* 5 was k_scanw (one ring shared by the 4 waves of a workgroup): measured no faster than k_scan, removed in round 3 */
 #define FIXCA_K_ROLL    6   /* LDS ring, horizontal-first rolling window (fixca_roll.hip) */
 #define FIXCA_K_WCOL    7   /* u16 / u32 / float / double samples: fp64 rolling window (fixca_wide.hip) */
 

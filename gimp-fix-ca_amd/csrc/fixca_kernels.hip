@@ -753,7 +753,6 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 		}
 		break;
 	case FIXCA_K_SCAN:
-	case FIXCA_K_SCANW:
 		return fixca_launch_scan(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_WCOL:
 		return fixca_launch_wide(d_src, d_dst, g, pl, stream);

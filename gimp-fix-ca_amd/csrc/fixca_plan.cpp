@@ -225,25 +225,17 @@ static bool plan_scan(const FixcaGeom *g, FixcaPlan *pl)
 	if ((long long)g->W * g->H * 4 >= (1LL << 40)) return false;
 	const int taps = (g->interp == 0) ? 0 : (g->interp == 1 ? 2 : 4);
 	const int span = scan_row_span(g, taps);
-	const bool shared = fixca_debug_flag("FIXCA_SCANW");  /* 4-wave shared-ring variant only on request (it is not faster yet) */
+	/* a block of 4 output rows keeps span + 3 rows alive; leave >= 4 slots for rows in flight */
 	int ring = env_int("FIXCA_RING", 0, 0, 64);
-	if (shared) {
-		/* a group of 4 rows keeps span + 3 rows alive, the previous group 4 more, plus 8 in flight */
-		if (ring == 0) ring = (span + 3 + 4 + 8 + 3) & ~3;
-		if (ring > 64 || span + 3 + 4 + 2 > ring) return false;
-	} else {
-		/* a block of 4 output rows keeps span + 3 rows alive; leave >= 4 slots for rows in flight */
-		if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : 32;
-		if ((ring & (ring - 1)) || span + 5 > ring) return false;
-	}
+	if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : 32;
+	if ((ring & (ring - 1)) || span + 5 > ring) return false;
 	int oc_max = env_int("FIXCA_OC", 252, 64, 252) & ~3;
 	for (int oc = oc_max; oc >= 128; oc -= 4) {
 		if (!scan_cols_fit(g, oc, taps)) continue;
-		pl->kernel = shared ? FIXCA_K_SCANW : FIXCA_K_SCAN;
+		pl->kernel = FIXCA_K_SCAN;
 		pl->oc = oc;
 		pl->th = env_int("FIXCA_TH", 64, 1, 4096);
 		pl->ring = ring;
-		pl->ablate = env_int("FIXCA_ABLATE", 0, 0, 3);
 		int rows = g->y2 - g->y1;
 		pl->nstrips = (g->W + oc - 1) / oc;
 		pl->nchunks = (rows + pl->th - 1) / pl->th;
@@ -371,7 +363,6 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	for (int oc = oc_pick; oc >= 128; oc = 0) {
 		const int rows = g->y2 - g->y1;
 		pl->kernel = FIXCA_K_ROLL;
-		pl->ablate = env_int("FIXCA_ABLATE", 0, 0, 15);
 		pl->oc = oc;
 		pl->ring = ring;
 		pl->nstrips = (g->W + oc - 1) / oc;
@@ -557,8 +548,8 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_SCANW", "FIXCA_RING", "FIXCA_OC",
-                                        "FIXCA_TH", "FIXCA_ABLATE" };
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
+                                        "FIXCA_TH" };
 
 static void env_signature(char *buf, size_t n)
 {
@@ -653,7 +644,7 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 	else if (pl->kernel == FIXCA_K_WCOL)
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
 		         pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->wide_fast ? " weights+recheck" : "");
-	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_SCANW || pl->kernel == FIXCA_K_ROLL)
+	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);
 	else

@@ -1,5 +1,6 @@
 /*
- * fixca_roll.hip — the row-rolling kernel (RGBA8, LINEAR / CUBIC): the main kernel of the path.
+ * fixca_roll.hip — the row-rolling kernel (RGBA8 and, compiled a second time through fixca_roll_rgb.hip,
+ * RGB8; NONE / LINEAR / CUBIC): the main kernel of the path.
  *
  * Same data movement as the LDS-ring scan kernel (fixca_scan.hip):
  *
@@ -138,23 +139,27 @@ __device__ __forceinline__ float next_lane_ubyte2(uint32_t v)
 	return f;
 }
 
-/* FIXCA_EXP_STAMPS (timing experiment only, output image is overwritten with the numbers):
- * s_memtime at the seams of a 4-row block, accumulated per wave */
-#if defined(FIXCA_EXP_STAMPS)
-#define STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st.acc[i] += t_ - st.last; st.last = t_; } while (0)
+/* Timing instrumentation lives in exp/fixca_roll_exp.h and is compiled in only with -DFIXCA_EXPERIMENTS
+ * (never in the shipped library: such a build overwrites the output image with its numbers). */
+#if defined(FIXCA_EXPERIMENTS)
+#include "exp/fixca_roll_exp.h"
 #else
-#define STAMP(i) do { } while (0)
+#define ROLL_EXP_FIELDS
+#define STAMP(i)                      do { } while (0)
+#define ROLL_EXP_BEGIN(st)            do { } while (0)
+#define ROLL_EXP_SINK(acc, NR)        do { } while (0)
+#define ROLL_EXP_END(st, dst, lane, gen) do { } while (0)
 #endif
 
 template <int TAPS, bool P2>          /* P2: the ring has a power-of-two number of rows */
 struct RollState {
-#if defined(FIXCA_EXP_STAMPS)
-	unsigned long long last, acc[8];
-#endif
+	ROLL_EXP_FIELDS
 	static constexpr int T = TAPS;
 	int      lane;
-	int      tap[2];            /* byte offset (may be negative) of my 4-pixel window in a ring row */
+	int      tap[2];            /* byte offset (may be negative) of my 4-pixel window in a ring row; RGB8: rounded down to a dword */
+#if ROLL_BPP == 3
+	int      rr[2];             /* RGB8: the window's bytes past that dword boundary, 0..3: the same for every lane (12 bytes per lane) */
+#endif
 	uint32_t my_idt;            /* byte offset of my 4 output pixels' own source pixels            */
 	/* ring */
 	uint8_t *ring;
@@ -226,9 +231,6 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
 {
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) roll_issue(st);
-#if defined(FIXCA_EXP_NOVMWAIT)                 /* timing experiment only: reads rows that may not have landed */
-	return;
-#endif
 	constexpr int LPR = 1 + ((ROLL_BPP == 4 && ROLL_WIN > 256) ? 1 : 0);     /* loads per row (RGB8: one DMA whatever the window) */
 	const int younger = st.ld - need;
 	if (younger >= 8) roll_wait_vm<8 * LPR>();
@@ -258,67 +260,93 @@ __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int
  * RGBA: 16 bytes at a 4-byte aligned address.  A ds_read_b128 from an address that is not 16-byte
  * aligned returns the right data on gfx950 but takes ~65 LDS cycles instead of 4 (measured), so
  * the access is left to the compiler as 4-byte aligned: two ds_read2_b32.
- * RGB: 12 bytes at ANY byte address (3 bytes per pixel): the 16 bytes around them are read from
- * the 4-byte aligned address below and shifted down by the (wave-uniform) misalignment. */
+ * RGB: 12 bytes at ANY byte address (3 bytes per pixel): the 16 bytes around them are read from the dword
+ * boundary below (st.tap is that boundary); the bytes are picked out where they are converted. */
 template <int TAPS, bool P2>
 __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2> &st, int row, int off)
 {
-#if defined(FIXCA_EXP_ALIGNED)                  /* timing experiment only: wrong pixels */
-	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~15));
-#elif ROLL_BPP == 4
 	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, v.d };
-#else
-	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~3));
-	const uint32_t r = (uint32_t)off & 3u;
-	return u32x4{ __builtin_amdgcn_alignbyte(v.b, v.a, r), __builtin_amdgcn_alignbyte(v.c, v.b, r),
-	              __builtin_amdgcn_alignbyte(v.d, v.c, r), 0u };
-#endif
 }
 
 #if ROLL_BPP == 3
-/* the dword lane L + 1 holds (0 in lane 63); the sources here are VALU results, so the shift is
- * left to the compiler, which knows the DPP hazards */
-__device__ __forceinline__ uint32_t next_lane_dword(uint32_t v)
+/* RGB8 tap windows.  A lane's 4 pixels are 12 bytes starting R = 0..3 bytes past a dword boundary, the next lane's
+ * 12 bytes follow directly (its own 16 bytes read starts 12 bytes on): sample c (0 red, 2 blue) of window pixel j is
+ * byte R + 3 j + c of my 4 dwords for j < 4 and byte R + 3 (j - 4) + c of lane L + 1's for j >= 4.  R depends on the
+ * strip and the channel only (12 bytes per lane keep it the same for every lane), so it is wave-uniform: one scalar
+ * branch per block and channel picks the instantiation whose v_cvt_f32_ubyteN carry the right dword and byte as
+ * constants.  Round 2 shifted the 16 bytes down by R first (three v_alignbyte per window read) and moved the next
+ * lane's dwords over with v_mov_dpp before converting: 86 VALU instructions per wave and row against RGBA8's 69,
+ * which is what held RGB8 11 points below RGBA8 (DESIGN.md §4 finding 6).  Here the conversion IS the byte pick,
+ * and the DPP shift rides on it as for RGBA.  The sources are LDS-load results, never fresh VALU results
+ * (tests/test_isa_checks.py), so the hand-written DPP forms need no wait states. */
+template <int K> __device__ __forceinline__ float own_ubyte(uint32_t v)
 {
-	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+	return (float)((v >> (8 * K)) & 0xffu);                         /* v_cvt_f32_ubyteK */
 }
-__device__ __forceinline__ float ubyte_f32(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+template <int K> __device__ __forceinline__ float next_lane_ubyte(uint32_t v)
+{
+	float f;
+	if constexpr (K == 0) asm("v_cvt_f32_ubyte0_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f) : "v"(v));
+	else if constexpr (K == 1) asm("v_cvt_f32_ubyte1_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f) : "v"(v));
+	else if constexpr (K == 2) asm("v_cvt_f32_ubyte2_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f) : "v"(v));
+	else asm("v_cvt_f32_ubyte3_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f) : "v"(v));
+	return f;
+}
+/* window pixels 0 .. NP-1 of NR source rows, channel byte C (0 red, 2 blue), misalignment R, into component C / 2 of tp */
+template <int R, int C, int NR, int NP>
+__device__ __forceinline__ void rgb_cvt_rows(const u32x4 (&p)[NR], f32x2 (&tp)[NR][NP])
+{
+#pragma unroll
+	for (int n = 0; n < NR; ++n) {
+#define RGB_PX(J) \
+		if constexpr (NP > J) { \
+			constexpr int B = R + 3 * ((J) & 3) + C; \
+			float f; \
+			if constexpr ((J) < 4) f = own_ubyte<B % 4>(p[n][B / 4]); else f = next_lane_ubyte<B % 4>(p[n][B / 4]); \
+			if constexpr (C == 0) tp[n][J].x = f; else tp[n][J].y = f; \
+		}
+		RGB_PX(0) RGB_PX(1) RGB_PX(2) RGB_PX(3) RGB_PX(4) RGB_PX(5) RGB_PX(6) RGB_PX(7)
+#undef RGB_PX
+	}
+}
+template <int C, int NR, int NP>
+__device__ __forceinline__ void rgb_cvt(int r, const u32x4 (&p)[NR], f32x2 (&tp)[NR][NP])
+{
+	switch (r) {                                                     /* wave-uniform: a scalar branch */
+	case 0:  rgb_cvt_rows<0, C, NR, NP>(p, tp); break;
+	case 1:  rgb_cvt_rows<1, C, NR, NP>(p, tp); break;
+	case 2:  rgb_cvt_rows<2, C, NR, NP>(p, tp); break;
+	default: rgb_cvt_rows<3, C, NR, NP>(p, tp); break;
+	}
+}
 #endif
 
-/* the 8 (NP used) pixels of my window of one source row per channel, as (red, blue) floats.
+/* the 8 (NP used) pixels of the windows of NR source rows per channel, as (red, blue) floats.
  * pr / pb: my 4 pixels; with the 272-column window every lane has also read the next 4 (nr / nb),
  * with the 256-column window they come from lane L + 1 over DPP. */
-template <int NP>
-__device__ __forceinline__ void roll_px8(const u32x4 &pr, const u32x4 &pb, const u32x4 &nr, const u32x4 &nb, f32x2 (&tp)[NP])
+template <int TAPS, bool P2, int NR, int NP>
+__device__ __forceinline__ void roll_px8(const RollState<TAPS, P2> &st, const u32x4 (&pr)[NR], const u32x4 (&pb)[NR],
+                                         const u32x4 (&nr)[NR], const u32x4 (&nb)[NR], f32x2 (&tp)[NR][NP])
 {
 #if ROLL_BPP == 4
 #pragma unroll
-	for (int k = 0; k < 4; ++k)
-		tp[k] = f32x2{ (float)(pr[k] & 0xffu), (float)((pb[k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
+	for (int n = 0; n < NR; ++n) {
 #pragma unroll
-	for (int k = 4; k < NP; ++k)
+		for (int k = 0; k < 4; ++k)
+			tp[n][k] = f32x2{ (float)(pr[n][k] & 0xffu), (float)((pb[n][k] >> 16) & 0xffu) };       /* v_cvt_f32_ubyte0 / ubyte2 */
+#pragma unroll
+		for (int k = 4; k < NP; ++k)
 #if ROLL_NEXT_FROM_LDS
-		tp[k] = f32x2{ (float)(nr[k - 4] & 0xffu), (float)((nb[k - 4] >> 16) & 0xffu) };
+			tp[n][k] = f32x2{ (float)(nr[n][k - 4] & 0xffu), (float)((nb[n][k - 4] >> 16) & 0xffu) };
 #else
-		tp[k] = f32x2{ next_lane_ubyte0(pr[k - 4]), next_lane_ubyte2(pb[k - 4]) };
+			tp[n][k] = f32x2{ next_lane_ubyte0(pr[n][k - 4]), next_lane_ubyte2(pb[n][k - 4]) };
 #endif
+	}
 #else
-	/* 12 bytes [R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3]: red of pixel k is byte 3k, blue byte 3k + 2 */
-	tp[0] = f32x2{ ubyte_f32(pr[0], 0), ubyte_f32(pb[0], 2) };
-	tp[1] = f32x2{ ubyte_f32(pr[0], 3), ubyte_f32(pb[1], 1) };
-	tp[2] = f32x2{ ubyte_f32(pr[1], 2), ubyte_f32(pb[2], 0) };
-	tp[3] = f32x2{ ubyte_f32(pr[2], 1), ubyte_f32(pb[2], 3) };
-#if ROLL_NEXT_FROM_LDS
-	const uint32_t nr0 = nr[0], nr1 = nr[1], nr2 = nr[2], nb0 = nb[0], nb1 = nb[1], nb2 = nb[2];
-#else
-	const uint32_t nr0 = next_lane_dword(pr[0]), nr1 = next_lane_dword(pr[1]), nr2 = next_lane_dword(pr[2]);
-	const uint32_t nb0 = next_lane_dword(pb[0]), nb1 = next_lane_dword(pb[1]), nb2 = next_lane_dword(pb[2]);
-#endif
-	if (NP > 4) tp[4] = f32x2{ ubyte_f32(nr0, 0), ubyte_f32(nb0, 2) };
-	if (NP > 5) tp[5 < NP ? 5 : 0] = f32x2{ ubyte_f32(nr0, 3), ubyte_f32(nb1, 1) };
-	if (NP > 6) tp[6 < NP ? 6 : 0] = f32x2{ ubyte_f32(nr1, 2), ubyte_f32(nb2, 0) };
-	if (NP > 7) tp[7 < NP ? 7 : 0] = f32x2{ ubyte_f32(nr2, 1), ubyte_f32(nb2, 3) };
+	static_assert(!ROLL_NEXT_FROM_LDS, "RGB8 takes the neighbour pixels over DPP");
+	rgb_cvt<0, NR, NP>(st.rr[0], pr, tp);
+	rgb_cvt<2, NR, NP>(st.rr[1], pb, tp);
 #endif
 }
 
@@ -339,15 +367,15 @@ template <int TAPS, bool P2, int NW>
 __device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5],
                                           int rowR, int rowB, f32x2 (&h)[4])
 {
-	const u32x4 pr = roll_ring_win(st, rowR, st.tap[0]), nr = roll_ring_next(st, rowR, st.tap[0]);
-	const u32x4 pb = roll_ring_win(st, rowB, st.tap[1]), nb = roll_ring_next(st, rowB, st.tap[1]);
-	f32x2 tp[NW + 3];
-	roll_px8<NW + 3>(pr, pb, nr, nb, tp);
+	const u32x4 pr[1] = { roll_ring_win(st, rowR, st.tap[0]) }, nr[1] = { roll_ring_next(st, rowR, st.tap[0]) };
+	const u32x4 pb[1] = { roll_ring_win(st, rowB, st.tap[1]) }, nb[1] = { roll_ring_next(st, rowB, st.tap[1]) };
+	f32x2 tp[1][NW + 3];
+	roll_px8<TAPS, P2, 1, NW + 3>(st, pr, pb, nr, nb, tp);
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		f32x2 a = wx[i][0] * tp[i];
+		f32x2 a = wx[i][0] * tp[0][i];
 #pragma unroll
-		for (int t = 1; t < NW; ++t) a = __builtin_elementwise_fma(wx[i][t], tp[i + t], a);
+		for (int t = 1; t < NW; ++t) a = __builtin_elementwise_fma(wx[i][t], tp[0][i + t], a);
 		h[i] = a;
 	}
 }
@@ -469,19 +497,9 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rows[t][k] = st.hist[t][k];
 
-#if defined(FIXCA_EXP_NOFILTER)                 /* timing experiment only: wrong pixels */
-#pragma unroll
-	for (int n = 0; n < NR; ++n)
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			acc[n][k] = f32x2{ (float)(pr[n][k] & 0xffu), (float)((pb[n][k] >> 16) & 0xffu) } * wy[n][0];
-			rows[T - 1 + n][k] = acc[n][k];
-		}
-#else
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
-#pragma unroll
-	for (int n = 0; n < NR; ++n) roll_px8<NP>(pr[n], pb[n], nr[n], nb[n], tp[n]);
+	roll_px8<TAPS, P2, NR, NP>(st, pr, pb, nr, nb, tp);
 #pragma unroll
 	for (int t = 0; t < NW; ++t)
 #pragma unroll
@@ -499,19 +517,11 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
 				acc[n][k] = __builtin_elementwise_fma(wy[n][t], rows[n + t][k], (t == 0) ? f32x2{ ROUND_BIAS, ROUND_BIAS } : acc[n][k]);
-#endif
 #pragma unroll
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
 		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[NR + t][k];
-#if defined(FIXCA_EXP_STAMPS)
-	{ float sink = 0.f;                             /* make the arithmetic finish before the stamp */
-#pragma unroll
-	  for (int n = 0; n < NR; ++n)
-#pragma unroll
-		for (int k = 0; k < 4; ++k) sink += acc[n][k].x + acc[n][k].y;
-	  asm volatile("v_readfirstlane_b32 s0, %0" :: "v"(sink) : "s0"); }
-#endif
+	ROLL_EXP_SINK(acc, NR);
 	STAMP(3);                                       /* filter arithmetic */
 #pragma unroll
 	for (int n = 0; n < NR; ++n) roll_store(st, acc[n], idt[n]);
@@ -533,12 +543,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 
 	RollState<TAPS, P2> st;
 	st.lane = threadIdx.x;
-#if defined(FIXCA_EXP_STAMPS)
-	st.last = __builtin_amdgcn_s_memtime();
-	const unsigned long long t_begin = st.last;
-	const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-	for (int i = 0; i < 8; ++i) st.acc[i] = 0;
-#endif
+	ROLL_EXP_BEGIN(st);
 	st.KM = pl.ring - 1;
 	st.kmagic = (uint32_t)((0x100000000ull + (unsigned)pl.ring - 1) / (unsigned)pl.ring);
 	st.H = H;
@@ -593,6 +598,12 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	constexpr int NB = ROLL_NEXT_FROM_LDS ? 1 : 0;     /* 256-column window: lane nact serves as lane nact-1's DPP neighbour */
 	st.tap[0] = (hd.tapR + 4 * min(lane, nact - NB)) * ROLL_BPP;
 	st.tap[1] = (hd.tapB + 4 * min(lane, nact - NB)) * ROLL_BPP;
+#if ROLL_BPP == 3
+	st.rr[0] = (hd.tapR * 3) & 3;                    /* scalar: the strip header comes from scalar loads */
+	st.rr[1] = (hd.tapB * 3) & 3;
+	st.tap[0] &= ~3;
+	st.tap[1] &= ~3;
+#endif
 	st.my_idt = (uint32_t)((X0 - U0) + 4 * min(lane, nact - 1)) * ROLL_BPP;
 	/* a lane without output stores at the buffer's size: past the end whether or not the range
 	 * check adds the row offset (the size is below 2 GB, so the sum cannot wrap) */
@@ -619,28 +630,20 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 			b = bn;
 		}
 	};
-#if defined(FIXCA_EXP_STAMPS)
 	STAMP(5);                                       /* prologue */
-#endif
 	if (hd.gen) run(std::integral_constant<int, 5>{});
 	else        run(std::integral_constant<int, (T == 1) ? 2 : T>{});
-#if defined(FIXCA_EXP_STAMPS)
-	STAMP(0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if (lane < 8) {
-		unsigned long long v = st.acc[0];
-		for (int i = 1; i < 8; ++i) v = (lane == i) ? st.acc[i] : v;
-		if (lane == 6) v = st.last - t_begin;
-		if (lane == 7) v = hd.gen;
-		if (lane == 5) v = __builtin_amdgcn_s_memrealtime() - rt_begin;   /* 100 MHz ticks; replaces the prologue slot */
-		if (lane == 4) v = rt_begin;
-		reinterpret_cast<unsigned long long *>(dst)[(size_t)blockIdx.x * 8 + lane] = v;
-	}
-#endif
+	ROLL_EXP_END(st, dst, lane, hd.gen);
 }
 
+/* build option: hold the kernel to the registers that let N waves share a SIMD (-DROLL_WAVES_PER_EU=3: 168) */
+#ifdef ROLL_WAVES_PER_EU
+#define ROLL_OCC __attribute__((amdgpu_waves_per_eu(ROLL_WAVES_PER_EU, ROLL_WAVES_PER_EU)))
+#else
+#define ROLL_OCC
+#endif
 template <int TAPS, bool P2>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
-__global__ __launch_bounds__(64) void
+__global__ __launch_bounds__(64) ROLL_OCC void
 k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -650,16 +653,9 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 	const int bx = blockIdx.x;
 	const int img = bx / sc.pool_blocks;
 	const int bid = bx - img * sc.pool_blocks;
-	int tile = xcd_remap(bid, sc.pool_blocks);
-#if defined(FIXCA_EXP_ORDER)                    /* timing experiment: tile order */
-	if (pl.ablate == 1) tile = bid;                                  /* consecutive tiles on different XCDs */
-#endif
+	const int tile = xcd_remap(bid, sc.pool_blocks);
 	if (tile >= sc.pool_waves) return;
-	int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
-#if defined(FIXCA_EXP_ORDER)
-	if (pl.ablate == 2) { chunk = tile % sc.pool_chunks; strip = tile / sc.pool_chunks; }          /* strip-major within the XCD range */
-	if (pl.ablate == 3) { tile = bid; chunk = tile % sc.pool_chunks; strip = tile / sc.pool_chunks; }
-#endif
+	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
 	const int Y0 = g.y1 + chunk * sc.th;
 	roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0));
 }

@@ -1,5 +1,7 @@
 /*
- * fixca_scan.hip — the LDS-ring row-scan kernel (RGBA8), the main kernel of the path.
+ * fixca_scan.hip — the LDS-ring row-scan kernel (RGBA8): the planner's second choice, for 8-bit geometries the
+ * row-rolling kernel (fixca_roll.hip, the main kernel of the path) refuses: tap offsets that drift by more than
+ * one column over a strip (scales far from 1).
  *
  * One wave (a 64-thread workgroup) owns `oc` output columns x `th` output rows and
  * streams the source rows it needs exactly once:
@@ -486,368 +488,11 @@ k_scan(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	}
 }
 
-/* ======================================================================================
- * k_scanw: the same row scan with ONE ring shared by the 4 waves of a 256-thread workgroup.
- *
- * The single-wave kernel above needs ring + exchange = 18 KB of LDS per wave, which caps a CU
- * at 8 waves; at 2 waves per SIMD a wave cannot hide its own LDS and issue latencies.  Here a
- * workgroup owns the strip; wave w produces output rows r = 4g + w of every group g of 4 rows
- * and all 4 waves read the same ring, so the ring costs 1/4 per wave and 16 waves fit a CU.
- *   - source row a is fetched (LDS-DMA) by wave a & 3; before a group is consumed every wave
- *     waits (counted vmcnt) for its own rows up to the group's newest row, then one s_barrier
- *     makes all of them visible to all waves.  LDS-DMA stays in flight across the barrier.
- *   - a wave's rows are 4 apart, so its vertical windows are rebuilt from the ring for every
- *     row (2*TAPS 16-byte LDS reads) instead of sliding.
- *   - ring slots of rows older than the PREVIOUS group's oldest row are refilled, so a wave
- *     that is still consuming the previous group is never overwritten (one barrier per group
- *     is enough).
- *   - lane constants are computed once per workgroup: wave w does output pixel w of every lane
- *     and the four waves swap results through LDS.
- * ====================================================================================== */
-
-#define WVX_BYTES 2304                  /* per-wave exchange array (2 * VX_CH * 4 = 2112, padded) */
-#define WDEPTH 8                        /* source rows in flight beyond the newest row of the group */
-
-template <int TAPS>
-struct ScanW {
-	static constexpr int T = (TAPS == 0) ? 1 : TAPS;
-	static constexpr int NT = T + 3;
-	f32x2    wx[4][T];
-	uint32_t ta[2][NT];
-	int      nb[2][4];
-	uint32_t go[2][4];
-	uint32_t my_ring, my_idt, my_vx;
-	bool     active, allcons, edgeL, edgeR;
-	int      lane, wave;
-	/* row table of this wave: lane j describes group gbase + j, i.e. output row 4*(gbase+j) + wave */
-	int      t_rb[2], t_keep, t_need;   /* keep: oldest row of the group, need: newest row of the group */
-	float    t_wy[2][T];
-	uint8_t *ring, *vx;
-	int      K, H;
-	uint32_t kmagic;            /* ceil(2^32 / K) */
-	int      ld;                /* highest source row issued by the workgroup                  */
-	int      ld_slot;           /* ring slot of row ld                                          */
-	int      lastneed;
-	int      seq, seqtab, own_newest;   /* my vector-memory ops; lane s: seq of my load in slot s; my newest row */
-	const uint8_t *gld;
-	uint8_t *gout;
-	size_t   pitch;
-};
-
-template <int TAPS>
-__device__ __forceinline__ int w_slot(const ScanW<TAPS> &st, int row)
-{
-	return row - st.K * (int)__umulhi((uint32_t)row, st.kmagic);       /* row mod K, row < 2^24 */
-}
-
-template <int TAPS>
-__device__ __forceinline__ u32x4 w_ring_px(const ScanW<TAPS> &st, int row, uint32_t off)
-{
-	return *reinterpret_cast<const u32x4 *>(st.ring + w_slot(st, row) * RING_ROW + off);
-}
-
-/* bring the ring up to `target`; this wave issues the rows with (row & 3) == wave */
-template <int TAPS>
-__device__ __forceinline__ void w_topup(ScanW<TAPS> &st, int target)
-{
-	while (st.ld < target) {
-		++st.ld;
-		if (++st.ld_slot == st.K) st.ld_slot = 0;
-		if ((st.ld & 3) == st.wave) {
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st.gld),
-			                                 (__attribute__((address_space(3))) void *)(st.ring + st.ld_slot * RING_ROW), 16, 0, 0);
-			st.seqtab = (st.lane == st.ld_slot) ? st.seq : st.seqtab;
-			++st.seq;
-			st.own_newest = st.ld;
-		}
-		st.gld += st.pitch;
-	}
-}
-
-/* wait until my own loads of rows <= need have landed */
-template <int TAPS>
-__device__ __forceinline__ void w_wait_own(const ScanW<TAPS> &st, int need, int first_row)
-{
-	/* my newest row that is <= need */
-	int a = need - ((need - st.wave) & 3);
-	if (a > st.own_newest) a = st.own_newest;
-	if (a < first_row) return;                       /* none of mine is needed yet */
-	const int younger = st.seq - rl(st.seqtab, w_slot(st, a)) - 1;
-	constexpr int HI = 2 * (WDEPTH / 4);
-	if (younger >= HI) wait_vm<HI>();
-	else if (younger >= HI / 2) wait_vm<HI / 2>();
-	else wait_vm<0>();
-}
-
-template <int TAPS>          /* 0 = NONE, 2 = LINEAR, 4 = CUBIC */
-__global__ __launch_bounds__(256) void
-k_scanw(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, FixcaPlan pl)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	constexpr int T = ScanW<TAPS>::T;
-	constexpr int NT = ScanW<TAPS>::NT;
-	constexpr int BACK = (TAPS == 4) ? 1 : 0;
-
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int tile = xcd_remap(blockIdx.x, pl.nblocks);
-	if (tile >= pl.nwaves) return;                  /* whole workgroup leaves: no barrier is skipped */
-	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
-	const int W = g.W, H = g.H, oc = pl.oc;
-	int X0 = strip * oc;
-	if (X0 > W - oc) X0 = W - oc;
-	const int Y0 = g.y1 + chunk * pl.th;
-	const int nrows = min(pl.th, g.y2 - Y0);
-	const int ngroups = (nrows + 3) >> 2;
-
-	ScanW<TAPS> st;
-	st.lane = lane;
-	st.wave = wave;
-	st.K = pl.ring;
-	st.kmagic = (uint32_t)((0x100000000ull + (unsigned)pl.ring - 1) / (unsigned)pl.ring);
-	st.H = H;
-	st.pitch = (size_t)W * 4;
-	st.ring = lds;
-	/* 4 exchange arrays of WVX_BYTES; during the prologue the same bytes carry the lane constants
-	 * (4 pixels x 64 lanes x 9 dwords) from the wave that computed them to the other three */
-	uint8_t *const shared_consts = lds + (size_t)pl.ring * RING_ROW;
-	st.vx = shared_consts + (size_t)wave * WVX_BYTES;
-
-	/* ---- the 256-column source window of this strip (uniform) ------------------------ */
-	int lo = X0;
-#pragma unroll
-	for (int c = 0; c < 2; ++c) {
-		int a;
-		if constexpr (TAPS == 0) a = map_int(X0, g.xc, W, g.s[c], g.xs[c]);
-		else a = clampi((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - BACK, 0, W - 1);
-		lo = min(lo, a);
-	}
-	const int U0 = __builtin_amdgcn_readfirstlane(min(lo & ~3, W - FIXCA_WAVE_COLS));
-	st.edgeL = (U0 == 0);
-	st.edgeR = (U0 + FIXCA_WAVE_COLS == W);
-
-	/* ---- row mapping ------------------------------------------------------------------ */
-	auto row_of = [&](int y, int c, int &rb, float *wy) {
-		if constexpr (TAPS == 0) {
-			rb = map_int(y, g.yc, H, g.s[c], g.ys[c]);
-		} else {
-			double yd = map_dbl(y, g.yc, H, g.s[c], g.ys[c]);
-			int y0 = (int)floor(yd);
-			if (wy) tap_weights<T>(yd - (double)y0, wy);
-			rb = y0 - BACK;
-		}
-	};
-	auto keep_of = [&](int y) {                     /* oldest source row output row y touches */
-		int k = y;
-#pragma unroll
-		for (int c = 0; c < 2; ++c) { int rb; row_of(y, c, rb, nullptr); k = min(k, clampi(rb, 0, H - 1)); }
-		return k;
-	};
-	auto need_of = [&](int y) {                     /* newest source row output row y touches */
-		int n = y;
-#pragma unroll
-		for (int c = 0; c < 2; ++c) { int rb; row_of(y, c, rb, nullptr); n = max(n, clampi(rb + T - 1, 0, H - 1)); }
-		return n;
-	};
-	auto build_rows = [&](int gbase) {              /* lane j <- group gbase + j */
-		const int r0 = 4 * (gbase + lane);
-		const int ylast = Y0 + nrows - 1;
-		const int ymine = min(Y0 + r0 + wave, ylast);
-#pragma unroll
-		for (int c = 0; c < 2; ++c) row_of(ymine, c, st.t_rb[c], st.t_wy[c]);
-		st.t_keep = keep_of(min(Y0 + r0, ylast));
-		st.t_need = need_of(min(Y0 + r0 + 3, ylast));
-	};
-
-	st.lastneed = __builtin_amdgcn_readfirstlane(need_of(Y0 + nrows - 1));
-	build_rows(0);
-	const int first_row = rl(st.t_keep, 0);
-	st.ld = first_row - 1;
-	st.ld_slot = w_slot(st, first_row) - 1;          /* may be -1: the first ++ makes it 0 */
-	st.seq = 0;
-	st.seqtab = 0;
-	st.own_newest = first_row - 1;
-	st.gld = src + (size_t)first_row * st.pitch + (size_t)(U0 + 4 * lane) * 4;
-	/* start filling the ring before the fp64-heavy lane constants */
-	w_topup(st, min(min(rl(st.t_need, 0) + WDEPTH, first_row + st.K - 1), st.lastneed));
-
-	/* ---- lane constants, computed once per workgroup: wave w does output pixel w -------- */
-	const int nact = oc >> 2;
-	st.active = lane < nact;
-	const int xl = X0 + 4 * min(lane, nact - 1);
-	{
-		uint32_t *mine = reinterpret_cast<uint32_t *>(shared_consts) + (wave * 64 + lane) * 9;
-#pragma unroll
-		for (int c = 0; c < 2; ++c) {
-			if constexpr (TAPS == 0) {
-				int sx = map_int(xl + wave, g.xc, W, g.s[c], g.xs[c]);
-				mine[1 + c] = (uint32_t)clampi(sx - U0, 0, FIXCA_WAVE_COLS - 1) * 4 + 2 * c;
-			} else {
-				double xd = map_dbl(xl + wave, g.xc, W, g.s[c], g.xs[c]);
-				int x0 = (int)floor(xd);
-				float w[T];
-				tap_weights<T>(xd - (double)x0, w);
-#pragma unroll
-				for (int t = 0; t < T; ++t) mine[1 + c * 4 + t] = __builtin_bit_cast(uint32_t, w[t]);
-				const uint32_t n16 = (uint32_t)(clampi(x0 - BACK - U0, -1, FIXCA_WAVE_COLS + 2 - T) + 1);
-				if (c == 0) mine[0] = n16; else mine[0] |= n16 << 16;
-			}
-		}
-	}
-	/* raw barriers only: __syncthreads() would drain the LDS-DMA already in flight */
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	__builtin_amdgcn_s_barrier();
-	asm volatile("" ::: "memory");
-	bool cons = true;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const uint32_t *e = reinterpret_cast<const uint32_t *>(shared_consts) + (i * 64 + lane) * 9;
-#pragma unroll
-		for (int c = 0; c < 2; ++c) {
-			if constexpr (TAPS == 0) {
-				st.go[c][i] = e[1 + c];
-			} else {
-				st.nb[c][i] = (int)((e[0] >> (16 * c)) & 0xffffu) - 1;
-#pragma unroll
-				for (int t = 0; t < T; ++t) {
-					float w = __builtin_bit_cast(float, e[1 + c * 4 + t]);
-					if (c == 0) st.wx[i][t].x = w; else st.wx[i][t].y = w;
-				}
-			}
-		}
-	}
-	if constexpr (TAPS != 0) {
-#pragma unroll
-		for (int c = 0; c < 2; ++c) {
-#pragma unroll
-			for (int i = 0; i < 4; ++i) cons = cons && (st.nb[c][i] == st.nb[c][0] + i);
-#pragma unroll
-			for (int t = 0; t < NT; ++t) st.ta[c][t] = vx_addr(st.nb[c][0] + t) + c * VX_CH * 4;
-		}
-	}
-	st.allcons = (TAPS == 0) ? true : (__all(cons) != 0);
-	/* every wave has read the constants before any wave reuses these bytes as exchange arrays */
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	__builtin_amdgcn_s_barrier();
-	asm volatile("" ::: "memory");
-	st.my_ring = (uint32_t)lane * 16;
-	st.my_idt = (uint32_t)((X0 - U0) * 4) + (uint32_t)min(lane, nact - 1) * 16;
-	st.my_vx = (uint32_t)(lane + 1) * 4;
-	st.gout = dst + (size_t)(Y0 + wave) * st.pitch + (size_t)xl * 4;
-	const size_t ostep = 4 * st.pitch;
-
-	int keep_prev = first_row;
-	for (int gi = 0; gi < ngroups; ++gi) {
-		const int j = gi & 63;
-		if (gi && j == 0) build_rows(gi);
-		const int keep = rl(st.t_keep, j), need = rl(st.t_need, j);
-		w_topup(st, min(min(need + WDEPTH, keep_prev + st.K - 1), st.lastneed));
-		keep_prev = keep;
-		if (!(pl.ablate & 2)) w_wait_own(st, need, first_row);
-		__builtin_amdgcn_s_barrier();                /* all rows <= need, from all 4 waves, are in LDS */
-
-		const int r = 4 * gi + wave;
-		if (r < nrows) {
-			const int y = Y0 + r;
-			const u32x4 idt = w_ring_px(st, y, st.my_idt);
-			u32x4 out;
-			if constexpr (TAPS == 0) {
-				const uint8_t *rowR = st.ring + w_slot(st, rl(st.t_rb[0], j)) * RING_ROW;
-				const uint8_t *rowB = st.ring + w_slot(st, rl(st.t_rb[1], j)) * RING_ROW;
-				uint32_t rq = 0, bq = 0;
-#pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					rq |= (uint32_t)rowR[st.go[0][i]] << (8 * i);
-					bq |= (uint32_t)rowB[st.go[1][i]] << (8 * i);
-				}
-				out.x = (idt.x & 0xFF00FF00u) | perm(bq, rq, 0x0c040c00);
-				out.y = (idt.y & 0xFF00FF00u) | perm(bq, rq, 0x0c050c01);
-				out.z = (idt.z & 0xFF00FF00u) | perm(bq, rq, 0x0c060c02);
-				out.w = (idt.w & 0xFF00FF00u) | perm(bq, rq, 0x0c070c03);
-			} else if (pl.ablate & 1) {
-				out = idt;
-			} else {
-				const int rbR = rl(st.t_rb[0], j), rbB = rl(st.t_rb[1], j);
-				f32x2 v[4] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } };
-#pragma unroll
-				for (int t = 0; t < T; ++t) {
-					const u32x4 pr = w_ring_px(st, clampi(rbR + t, 0, H - 1), st.my_ring);   /* edge rows replicate */
-					const u32x4 pb = w_ring_px(st, clampi(rbB + t, 0, H - 1), st.my_ring);
-					const f32x2 wy = { rlf(st.t_wy[0][t], j), rlf(st.t_wy[1][t], j) };
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-						v[k] = __builtin_elementwise_fma(wy, rb_floats(pr[k], pb[k]), v[k]);
-				}
-				/* publish to my exchange array, gather the horizontal taps, filter */
-				float *const vr = reinterpret_cast<float *>(st.vx + st.my_vx);
-				float *const vb = reinterpret_cast<float *>(st.vx + st.my_vx + VX_CH * 4);
-#pragma unroll
-				for (int k = 0; k < 4; ++k) { vr[k * VX_PS] = v[k].x; vb[k * VX_PS] = v[k].y; }
-				if (st.edgeL && lane == 0) { vr[3 * VX_PS - 1] = v[0].x; vb[3 * VX_PS - 1] = v[0].y; }
-				if (st.edgeR && lane == 63) {
-					vr[0 * VX_PS + 1] = v[3].x; vr[1 * VX_PS + 1] = v[3].x;
-					vb[0 * VX_PS + 1] = v[3].y; vb[1 * VX_PS + 1] = v[3].y;
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				f32x2 acc[4] = { { ROUND_BIAS, ROUND_BIAS }, { ROUND_BIAS, ROUND_BIAS }, { ROUND_BIAS, ROUND_BIAS }, { ROUND_BIAS, ROUND_BIAS } };
-				if (st.allcons) {
-					f32x2 tp[NT];
-#pragma unroll
-					for (int t = 0; t < NT; ++t) {
-						tp[t].x = *reinterpret_cast<const float *>(st.vx + st.ta[0][t]);
-						tp[t].y = *reinterpret_cast<const float *>(st.vx + st.ta[1][t]);
-					}
-#pragma unroll
-					for (int i = 0; i < 4; ++i)
-#pragma unroll
-						for (int t = 0; t < TAPS; ++t)
-							acc[i] = __builtin_elementwise_fma(st.wx[i][t], tp[i + t], acc[i]);
-				} else {
-#pragma unroll
-					for (int i = 0; i < 4; ++i)
-#pragma unroll
-						for (int t = 0; t < TAPS; ++t) {
-							f32x2 tp;
-							tp.x = *reinterpret_cast<const float *>(st.vx + vx_addr(st.nb[0][i] + t));
-							tp.y = *reinterpret_cast<const float *>(st.vx + vx_addr(st.nb[1][i] + t) + VX_CH * 4);
-							acc[i] = __builtin_elementwise_fma(st.wx[i][t], tp, acc[i]);
-						}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].x, 0, idt[k]);
-					out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
-				}
-			}
-			if (st.active)
-				__builtin_nontemporal_store(out, reinterpret_cast<u32x4 *>(st.gout));
-		}
-		st.gout += ostep;
-	}
-}
-
 extern "C" hipError_t
 fixca_launch_scan(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
 	const uint8_t *s = static_cast<const uint8_t *>(d_src);
 	uint8_t *d = static_cast<uint8_t *>(d_dst);
-	if (pl->kernel == FIXCA_K_SCANW) {
-		const size_t ldsw = (size_t)pl->ring * RING_ROW + 4 * WVX_BYTES;
-		static std::once_flag wattr;
-		std::call_once(wattr, [] {
-			(void)hipFuncSetAttribute((const void *)k_scanw<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			(void)hipFuncSetAttribute((const void *)k_scanw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			(void)hipFuncSetAttribute((const void *)k_scanw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		});
-		if (g->interp == 0)      hipLaunchKernelGGL(k_scanw<0>, dim3(pl->nblocks), dim3(256), ldsw, stream, s, d, *g, *pl);
-		else if (g->interp == 1) hipLaunchKernelGGL(k_scanw<2>, dim3(pl->nblocks), dim3(256), ldsw, stream, s, d, *g, *pl);
-		else                     hipLaunchKernelGGL(k_scanw<4>, dim3(pl->nblocks), dim3(256), ldsw, stream, s, d, *g, *pl);
-		return hipGetLastError();
-	}
 	const size_t lds = (size_t)pl->ring * RING_ROW + 2 * VX_CH * 4;
 	static std::once_flag attr_once;
 	std::call_once(attr_once, [] {

@@ -756,8 +756,6 @@ VARIANTS = {
     "scan": {"FIXCA_NO_ROLL": "1"},               # LDS-ring scan with the exchange array, one wave per strip
     "scan-th7": {"FIXCA_NO_ROLL": "1", "FIXCA_TH": "7"},
     "scan-th200": {"FIXCA_NO_ROLL": "1", "FIXCA_TH": "200"},
-    "scanw": {"FIXCA_NO_ROLL": "1", "FIXCA_SCANW": "1"},   # ring shared by the 4 waves of a workgroup
-    "scanw-th13": {"FIXCA_NO_ROLL": "1", "FIXCA_SCANW": "1", "FIXCA_TH": "13"},
     "regwin": {"FIXCA_NO_ROLL": "1", "FIXCA_NO_SCAN": "1"},   # register-window kernels
 }
 SCAN_SHAPES = [(256, 70), (260, 33), (512, 300), (1000, 50), (1024, 257), (2048, 72)]
@@ -784,8 +782,6 @@ def test_kernel_variants_agree_with_oracle(torch_cuda, monkeypatch, variant, sha
             assert kid in (2, 3, 4, 6), desc             # a forced ring size may fit neither ring kernel
             if pi in (0, 2) and w >= 2048:
                 assert kid == 6, desc                       # mild scales: the rolling kernel must take these
-        elif variant.startswith("scanw"):
-            assert kid in (3, 5), desc
         elif variant.startswith("scan"):
             assert kid in (3, 4), desc
         else:
@@ -799,3 +795,33 @@ def test_kernel_variants_agree_with_oracle(torch_cuda, monkeypatch, variant, sha
         part = gpu_run(torch_cuda, img, p, fixca.KERNEL_FAST, y1=h // 3, y2=h - 5, fill=0x77)
         assert np.array_equal(part[h // 3:h - 5], out[h // 3:h - 5])
         assert np.all(part[:h // 3] == 0x77) and np.all(part[h - 5:] == 0x77)
+
+
+# ---- bench.py's N > 1 branch (BASELINE configs[4]: the batch sharded over the node's GPUs) ----------
+
+def test_bench_two_ranks_rehearsal(torch_cuda, repo_root):
+    """`python bench.py --gpus 2` starts its own two ranks (child processes, torch.distributed.run); with
+    FIXCA_BENCH_REHEARSE=1 they share this box's one GPU and talk over gloo.  The whole world > 1 control
+    flow runs: parameter broadcast from rank 0, image i -> rank i mod 2, per-rank timing and MAX reduce,
+    per-rank parity, the oracle check on image 0, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, FIXCA_BENCH_REHEARSE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--global-batch", "8",
+                        "--steps", "2", "--warmup", "1", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                         # ONE JSON line, everything else went to stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ok"] is True
+    assert out["steps"] == 2 and out["warmup"] == 1
+    cfg = out["config"]
+    assert cfg["global_batch"] == 8 and cfg["images_per_gpu_per_step"] == 4
+    assert cfg["images_by_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]]        # image i -> rank i mod 2
+    assert out["checks"]["held_images_are_the_owned_ones"] and out["checks"]["within_1_lsb_of_fp64_kernel"]
+    assert out["parity_vs_oracle"]["max_abs_diff"] <= 1 and out["parity_vs_oracle"]["green_alpha_equal"]
+    assert out["roofline"]["kernel"].startswith("k_roll<4")
+    assert out["value"] > 0 and out["roofline"]["images_per_launch"] == 4

@@ -1,5 +1,6 @@
 """CPU tests of the host-side logic: the planner's strip widths against a numpy
 model of the row-scan kernel, and the model against the oracle (<= 1 LSB)."""
+import os
 import re
 
 import numpy as np
@@ -132,3 +133,24 @@ def test_no_store_data_hazard_in_kernels(tmp_path):
                         os.path.join(root, "gimp-fix-ca_amd", "csrc", src), "-o", str(out)], check=True, capture_output=True)
         direct = [h for h in store_hazard_scan.scan(str(out)) if "(+1)" in h]
         assert not direct, direct[:3]
+
+
+def test_bench_launcher_relays_the_ranks_exit_code(repo_root):
+    """`python bench.py --gpus 2` without WORLD_SIZE starts its own ranks as child processes and returns
+    their exit code.  On a machine without a GPU the ranks refuse to run: the launcher must say so with a
+    non-zero code and no result line (a driver must never read a number out of a failed run)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the command would run the real bench (tests/test_gpu_parity.py covers that)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--global-batch", "4",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "no GPU visible" in r.stderr
+    # asking for N ranks while a different world is already set up is refused, not silently re-interpreted
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
