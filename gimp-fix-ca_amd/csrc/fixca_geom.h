@@ -35,7 +35,7 @@ struct FixcaPlan {
 	int nblocks;        /* workgroups, padded to a multiple of 8 (256 threads
 	                       for kernels 2,3; one 64-thread wave for kernel 4)  */
 	int ring;           /* kernels 4, 6, 8: source rows in the LDS ring         */
-	int reserved_;      /* (was an experiment switch; kept so the struct's layout does not move) */
+	int nu;             /* kernel 8: KiB per ring row = 16-byte units a lane moves per output row (1, 2, 4) */
 	int wide_fast;      /* kernel 7, 16-bit samples, CUBIC: the weight form with exact recomputation of the
 	                       samples near a rounding boundary (fixca_wide.hip); 0 = operation for operation */
 };
@@ -47,6 +47,7 @@ struct FixcaPlan {
 /* 5 was k_scanw (one ring shared by the 4 waves of a workgroup): measured no faster than k_scan, removed in round 3 */
 #define FIXCA_K_ROLL    6   /* LDS ring, horizontal-first rolling window (fixca_roll.hip) */
 #define FIXCA_K_WCOL    7   /* u16 / u32 / float / double samples: fp64 rolling window (fixca_wide.hip) */
+#define FIXCA_K_MOVE    8   /* u16 / u32 / float / double samples, NONE: LDS-ring byte mover (fixca_move.hip) */
 
 #define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
 

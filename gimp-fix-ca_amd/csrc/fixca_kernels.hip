@@ -720,6 +720,7 @@ extern "C" hipError_t fixca_launch_scan(const void *, void *, const FixcaGeom *,
 extern "C" hipError_t fixca_launch_roll(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_rgb(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_wide(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_move(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
 extern "C" hipError_t
 fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
@@ -756,6 +757,8 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 		return fixca_launch_scan(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_WCOL:
 		return fixca_launch_wide(d_src, d_dst, g, pl, stream);
+	case FIXCA_K_MOVE:
+		return fixca_launch_move(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_ROLL:
 		return g->bpp == 3 ? fixca_launch_roll_rgb(d_src, d_dst, g, pl, stream) : fixca_launch_roll(d_src, d_dst, g, pl, stream);
 	default:

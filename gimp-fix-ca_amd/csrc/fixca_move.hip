@@ -1,0 +1,311 @@
+/*
+ * fixca_move.hip — interpolation NONE on the sample types beyond 8 bits (u16, u32, float, double; RGB and RGBA):
+ * a byte mover.  NONE never looks at a sample's value: the reference copies the b bytes of the red and of the blue
+ * sample from the nearest source position and leaves green and alpha where they are (fix-ca.c:1100-1121, `memcpy`
+ * of b bytes at :1117-1120; the positions are scale(), fix-ca.c:799-809).  Bit-exact by construction.
+ *
+ * Structure of the row-rolling kernel (fixca_roll.hip), on raw bytes:
+ *
+ *   HBM/L2 --LDS-DMA--> ring of K source rows in LDS --> registers --> HBM (16-byte nt stores)
+ *
+ *  - one wave (a 64-thread workgroup) per tile of `ocpx` output columns x `th` rows.  A ring row holds the strip's
+ *    source window, NU KiB (NU = 1, 2 or 4 LDS-DMA instructions of 16 bytes per lane); every source row is fetched
+ *    once per wave and serves all three consumers: the identity copy (green, alpha) of output row y, the red samples
+ *    of the output row whose red source row it is, and the blue ones likewise.  (k_wcol's register queue, which ran
+ *    NONE on 16-bit samples in round 2, fetched it three times, the one-thread-per-pixel gather issued 3 loads per
+ *    pixel: 53 % and 58-63 % of the HBM roofline.)
+ *  - a lane owns NU 16-byte UNITS of the strip's output row (unit = lane + 64 i: every store instruction writes 1 KiB
+ *    of consecutive bytes).  The column map x' depends on the column only, so the byte offset in a ring row of every
+ *    sample a lane gathers is a per-lane constant for the whole tile, computed once with the reference's fp64
+ *    expression; the row map y' depends on the row only: per row three wave-uniform ring slots (identity, red, blue).
+ *      RGBA: the unit is read whole (ds_read_b128) and its red / blue samples are overwritten by 2-, 4- or 8-byte
+ *            LDS reads from the red / blue source row;
+ *      RGB:  units straddle pixels (16 is not a multiple of 6, 12 or 24), the channel of sample k of a unit depends on
+ *            the unit modulo 3: every sample is gathered, from the row its channel calls for.
+ *  - counted s_waitcnt vmcnt on the loads alone, rows prefetched MOVE_DEPTH ahead, as in k_roll.
+ *
+ * The planner (plan_move, fixca_plan.cpp) takes a geometry when every strip's window (identity columns + red and
+ * blue source columns) fits a ring row and rows are a whole number of dwords; everything else stays with
+ * k_wcol<.., 1> / the one-thread-per-pixel kernel.
+ */
+#include "fixca_device.h"
+#include "fixca_move.h"
+#include <mutex>
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int N> __device__ __forceinline__ void move_wait_vm()
+{
+	asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+/* row mod K for any K (wave-uniform operands: scalar multiply-high) */
+__device__ __forceinline__ int move_slot(int row, int K, uint32_t kmagic)
+{
+	return row - K * (int)__umulhi((uint32_t)row, kmagic);
+}
+
+/* smallest power of two a such that a * pb is a multiple of 16: ring windows start on such a column, so that the
+ * LDS-DMA's global address and the RGBA identity reads are 16-byte aligned relative to the row start */
+__host__ __device__ constexpr int move_col_align(int pb)
+{
+	return (pb % 16 == 0) ? 1 : (pb % 8 == 0) ? 2 : (pb % 4 == 0) ? 4 : 8;
+}
+
+template <int SB, int NCH, int NU>     /* SB: bytes per sample (2, 4, 8); NCH: samples per pixel; NU: KiB per ring row */
+__global__ __launch_bounds__(64) void
+k_move(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, MovePlan mp)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
+	constexpr int PB = SB * NCH;                       /* bytes per pixel                               */
+	constexpr int NS = 16 / SB;                        /* samples per unit                              */
+	constexpr int WINB = NU * 1024;                    /* bytes per ring row                            */
+	constexpr int NG = (NCH == 4) ? (SB == 8 ? 1 : NS / 2) : NS;     /* samples gathered per unit       */
+
+	const int lane = threadIdx.x;
+	const int W = g.W, H = g.H;
+	const int tile = xcd_remap(blockIdx.x, mp.nblocks);
+	if (tile >= mp.nwaves) return;
+	const int strip = tile % mp.nstrips, chunk = tile / mp.nstrips;
+	const int X0 = strip * mp.ocpx, xe = min(X0 + mp.ocpx, W);
+	const int Y0 = g.y1 + chunk * mp.th;
+	const int nrows = min(mp.th, g.y2 - Y0);
+	const uint32_t pitch = (uint32_t)W * PB;
+	const int K = mp.ring;
+	const uint32_t kmagic = (uint32_t)((0x100000000ull + (unsigned)K - 1) / (unsigned)K);
+
+	/* ---- the strip's window: the lowest column any consumer reads (the maps are monotone: the first column's) -------- */
+	int lo = X0;
+#pragma unroll
+	for (int c = 0; c < 2; ++c) lo = min(lo, map_int(X0, g.xc, W, g.s[c], g.xs[c]));
+	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(move_col_align(PB) - 1));
+
+	/* ---- per-lane constants: where in a ring row each sample of my units comes from ------------------------------------ */
+	const int nbytes = (xe - X0) * PB;                 /* bytes of the strip's output row (a multiple of 4) */
+	const int nunits = (nbytes + 15) >> 4;
+	const int tail_dw = (nbytes & 15) >> 2;            /* dwords of a last, partial unit (0: none)       */
+	uint32_t goff[NU][NG];                             /* byte offset in a ring row of gathered sample j */
+	uint32_t idoff[NU];                                /* RGBA: byte offset in a ring row of my unit      */
+	uint32_t stoff[NU];                                /* byte offset in an output row of my unit, or out of range */
+	int      chsel[NU];                                /* RGB: channel of sample 0 of the unit (0 R, 1 G, 2 B); RGBA double: 0 (R, G) or 2 (B, A) */
+#pragma unroll
+	for (int i = 0; i < NU; ++i) {
+		const int U = min(lane + 64 * i, nunits - 1);  /* units past the strip copy the last one's addresses and store nothing */
+		const int s0 = U * NS;                         /* first sample of the unit, counted from the strip's first pixel */
+		idoff[i] = (uint32_t)((X0 - U0) * PB + 16 * U);
+		chsel[i] = (NCH == 4) ? ((SB == 8) ? 2 * (U & 1) : 0) : s0 % 3;
+#pragma unroll
+		for (int j = 0; j < NG; ++j) {
+			/* sample index within the unit of gathered sample j: RGBA u16 / 4-byte: the red and blue ones (0, 2, 4, 6);
+			 * RGBA double: sample 0 (red in even units, blue in odd ones); RGB: every sample */
+			const int k = (NCH == 4) ? ((SB == 8) ? 0 : 2 * j) : j;
+			const int s = s0 + k;
+			const int px = min(X0 + s / NCH, W - 1), ch = s % NCH;
+			int sx = px;
+			if (ch == 0) sx = map_int(px, g.xc, W, g.s[0], g.xs[0]);
+			if (ch == 2) sx = map_int(px, g.xc, W, g.s[1], g.xs[1]);
+			goff[i][j] = (uint32_t)((sx - U0) * PB + ch * SB);
+		}
+	}
+
+	/* ---- global memory through buffer descriptors of this tile's rows (32-bit offsets whatever the image size) -------- */
+	int rowR_v = 0, rowB_v = 0;                        /* lane i: red / blue source row of output row (64-row segment base) + i */
+	auto row_tables = [&](int r0) {
+		const int y = min(Y0 + r0 + lane, g.y2 - 1);
+		rowR_v = map_int(y, g.yc, H, g.s[0], g.ys[0]);           /* fix-ca.c:1105-1106 */
+		rowB_v = map_int(y, g.yc, H, g.s[1], g.ys[1]);
+	};
+	row_tables(0);
+	const int yl = Y0 + nrows - 1;
+	const int keep0 = min(Y0, min(__builtin_amdgcn_readlane(rowR_v, 0), __builtin_amdgcn_readlane(rowB_v, 0)));
+	const int lastneed = max(yl, max(map_int(yl, g.yc, H, g.s[0], g.ys[0]), map_int(yl, g.yc, H, g.s[1], g.ys[1])));
+	const int lastneed_s = __builtin_amdgcn_readfirstlane(lastneed);
+	const uint32_t dst_bytes = (uint32_t)nrows * pitch;
+	const rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + (size_t)keep0 * pitch, 0,
+	                                                        (uint32_t)(lastneed_s - keep0 + 1) * pitch, 0x00020000);
+	const rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)Y0 * pitch, 0, dst_bytes, 0x00020000);
+#pragma unroll
+	for (int i = 0; i < NU; ++i) {
+		const int U = lane + 64 * i;
+		const bool whole = U < nunits - (tail_dw ? 1 : 0);
+		stoff[i] = whole ? (uint32_t)(X0 * PB + 16 * U) : dst_bytes;
+	}
+	const int tail_u = (nunits - 1) >> 6, tail_lane = (nunits - 1) & 63;
+
+	/* ---- the ring ------------------------------------------------------------------------------------------------------ */
+	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
+	int ld = keep0 - 1;
+	uint32_t so_ld = 0;
+	auto issue = [&]() {
+		++ld;
+		const int slot = move_slot(ld, K, kmagic);
+#if defined(__HIP_DEVICE_COMPILE__)
+		__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(ring + slot * WINB);
+		/* the instruction offset applies to the global and to the LDS address alike: piece i is bytes 1024 i .. of the window */
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void *)row, 16, vo_ld, so_ld, 0, 0);
+		if constexpr (NU > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void *)row, 16, vo_ld, so_ld, 1024, 0);
+		if constexpr (NU > 2) {
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void *)row, 16, vo_ld, so_ld, 2048, 0);
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void *)row, 16, vo_ld, so_ld, 3072, 0);
+		}
+#endif
+		so_ld += pitch;
+	};
+	/* rows in flight beyond `need`, within the ring's capacity; then wait until row `need` has landed.  vmcnt counts
+	 * loads and stores; the wait relies on the loads alone (rows are loaded in order, NU loads each): stores in flight
+	 * make it stricter, never wrong (fixca_roll.hip, roll_fetch) */
+	auto fetch = [&](int keep, int need) {
+		const int target = min(min(need + MOVE_DEPTH, keep + K - 1), lastneed_s);
+		while (ld < target) issue();
+		const int younger = ld - need;
+		if (younger >= 6) move_wait_vm<6 * NU>();
+		else if (younger >= 4) move_wait_vm<4 * NU>();
+		else if (younger >= 3) move_wait_vm<3 * NU>();
+		else if (younger >= 2) move_wait_vm<2 * NU>();
+		else if (younger >= 1) move_wait_vm<NU>();
+		else move_wait_vm<0>();
+	};
+
+	uint32_t so_st = 0;
+	for (int r = 0; r < nrows; ++r) {
+		if (r && (r & 63) == 0) row_tables(r);
+		const int y = Y0 + r;
+		const int rR = __builtin_amdgcn_readlane(rowR_v, r & 63), rB = __builtin_amdgcn_readlane(rowB_v, r & 63);
+		const int keep = min(y, min(rR, rB)), need = max(y, max(rR, rB));
+		/* every LDS read of the previous row has returned (its stores consumed them): the slots below `keep` are free */
+		fetch(keep, need);
+		const uint32_t bI = (uint32_t)move_slot(y, K, kmagic) * WINB, bR = (uint32_t)move_slot(rR, K, kmagic) * WINB,
+		               bB = (uint32_t)move_slot(rB, K, kmagic) * WINB;
+		u32x4 out[NU];
+#pragma unroll
+		for (int i = 0; i < NU; ++i) {
+			if constexpr (NCH == 4) {
+				u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
+				if constexpr (SB == 2) {
+					const uint32_t r0 = *reinterpret_cast<const uint16_t *>(ring + bR + goff[i][0]);
+					const uint32_t b0 = *reinterpret_cast<const uint16_t *>(ring + bB + goff[i][1]);
+					const uint32_t r1 = *reinterpret_cast<const uint16_t *>(ring + bR + goff[i][2]);
+					const uint32_t b1 = *reinterpret_cast<const uint16_t *>(ring + bB + goff[i][3]);
+					v.x = (v.x & 0xFFFF0000u) | r0; v.y = (v.y & 0xFFFF0000u) | b0;
+					v.z = (v.z & 0xFFFF0000u) | r1; v.w = (v.w & 0xFFFF0000u) | b1;
+				} else if constexpr (SB == 4) {
+					v.x = *reinterpret_cast<const uint32_t *>(ring + bR + goff[i][0]);
+					v.z = *reinterpret_cast<const uint32_t *>(ring + bB + goff[i][1]);
+				} else {
+					const u32x2 s = *reinterpret_cast<const u32x2 *>(ring + (chsel[i] ? bB : bR) + goff[i][0]);
+					v.x = s.x; v.y = s.y;
+				}
+				out[i] = v;
+			} else {
+				/* channel of sample k: (chsel + k) mod 3; its row: red's, this one, blue's */
+				uint32_t base[3];
+#pragma unroll
+				for (int j = 0; j < 3; ++j) {
+					const int c = (chsel[i] + j) % 3;
+					base[j] = (c == 0) ? bR : (c == 2) ? bB : bI;
+				}
+				uint32_t w[4];
+				if constexpr (SB == 2) {
+#pragma unroll
+					for (int d = 0; d < 4; ++d) {
+						const uint32_t a = *reinterpret_cast<const uint16_t *>(ring + base[(2 * d) % 3] + goff[i][2 * d]);
+						const uint32_t b = *reinterpret_cast<const uint16_t *>(ring + base[(2 * d + 1) % 3] + goff[i][2 * d + 1]);
+						w[d] = a | (b << 16);
+					}
+				} else if constexpr (SB == 4) {
+#pragma unroll
+					for (int d = 0; d < 4; ++d) w[d] = *reinterpret_cast<const uint32_t *>(ring + base[d % 3] + goff[i][d]);
+				} else {
+#pragma unroll
+					for (int d = 0; d < 2; ++d) {
+						const u32x2 s = *reinterpret_cast<const u32x2 *>(ring + base[d] + goff[i][d]);
+						w[2 * d] = s.x; w[2 * d + 1] = s.y;
+					}
+				}
+				out[i] = u32x4{ w[0], w[1], w[2], w[3] };
+			}
+		}
+		/* The row offset goes into the vector offset, the scalar offset stays the constant 0: with a register there the
+		 * compiler leaves no wait state between a 16-byte store and the next write of its data registers, and on MI355X the
+		 * store then carries the next row's bytes ("a hardware hazard"; tests/test_host_logic.py scans for it) */
+#pragma unroll
+		for (int i = 0; i < NU; ++i)
+			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);
+		if (tail_dw) {                                  /* wave-uniform: a strip whose row does not end on a unit boundary */
+#pragma unroll
+			for (int i = 0; i < NU; ++i)
+				if (i == tail_u) {
+					const uint32_t o = (lane == tail_lane) ? (uint32_t)(X0 * PB + 16 * (lane + 64 * i)) + so_st : dst_bytes;
+#pragma unroll
+					for (int d = 0; d < 3; ++d)
+						if (d < tail_dw) __builtin_amdgcn_raw_buffer_store_b32(out[i][d], rs_dst, o == dst_bytes ? dst_bytes : o + 4 * d, 0, 2);
+				}
+		}
+		so_st += pitch;
+		/* the next iteration overwrites ring slots: every LDS read above must have returned.  The stores consume the
+		 * data, so the compiler has waited already; the explicit wait costs nothing and does not depend on that */
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	}
+}
+
+template <int SB, int NCH>
+const void *move_kernel_nu(int nu)
+{
+	switch (nu) {
+	case 1:  return reinterpret_cast<const void *>(&k_move<SB, NCH, 1>);
+	case 2:  return reinterpret_cast<const void *>(&k_move<SB, NCH, 2>);
+	default: return reinterpret_cast<const void *>(&k_move<SB, NCH, 4>);
+	}
+}
+
+const void *move_kernel_for(const FixcaGeom *g, int nu)
+{
+	const int sb = g->bpc < 0 ? -g->bpc : g->bpc;
+	if (g->nch == 4) {
+		if (sb == 2) return move_kernel_nu<2, 4>(nu);
+		if (sb == 4) return move_kernel_nu<4, 4>(nu);
+		if (sb == 8) return move_kernel_nu<8, 4>(nu);
+	} else if (g->nch == 3) {
+		if (sb == 2) return move_kernel_nu<2, 3>(nu);
+		if (sb == 4) return move_kernel_nu<4, 3>(nu);
+		if (sb == 8) return move_kernel_nu<8, 3>(nu);
+	}
+	return nullptr;
+}
+
+}   /* namespace */
+
+extern "C" hipError_t
+fixca_launch_move(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+{
+	if (g->y2 <= g->y1) return hipSuccess;
+	if (g->interp != 0 || (pl->nu != 1 && pl->nu != 2 && pl->nu != 4)) return hipErrorInvalidValue;
+	const void *fn = move_kernel_for(g, pl->nu);
+	if (!fn) return hipErrorInvalidValue;
+	const size_t lds = (size_t)pl->ring * pl->nu * 1024;
+	if (lds > MOVE_LDS_MAX) return hipErrorInvalidValue;
+	/* dynamic LDS above the default limit needs the attribute once per function */
+	static std::mutex mu;
+	static const void *done[32];
+	static int ndone = 0;
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		bool seen = false;
+		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
+		if (!seen) {
+			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX);
+			if (ndone < 32) done[ndone++] = fn;
+		}
+	}
+	MovePlan mp;
+	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
+	const uint8_t *s = static_cast<const uint8_t *>(d_src);
+	uint8_t *d = static_cast<uint8_t *>(d_dst);
+	FixcaGeom geom = *g;
+	void *args[] = { &s, &d, &geom, &mp };
+	return hipLaunchKernel(fn, dim3((unsigned)mp.nblocks), dim3(64), args, lds, stream);
+}

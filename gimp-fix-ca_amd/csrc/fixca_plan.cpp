@@ -17,6 +17,7 @@
 #include "fixca_internal.h"
 #include "fixca_roll.h"
 #include "fixca_wide.h"
+#include "fixca_move.h"
 
 static double h_coord(int i, int centre, double s, double shift)
 {
@@ -390,10 +391,10 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			 * waves (4 x the rows a wave keeps alive, so the halo stays ~20 %) measure best:
 			 * 6000x4000, span 7: th 33 -> 35.2 us per image, 44 -> 36.0, 57 -> 37.4 */
 			best_th = 4 * span + 5;
-			/* RGB8 rows are 3/4 of the bytes for the same per-row work: shorter waves (more of them in flight per byte)
-			 * measure 0.7-0.9 points better on one allocation (tools/ab_rgb.py: th 21 65.3 %, 25 65.1, 29 64.5, 33 64.4,
-			 * 41 63.7, 57 60.0) */
-			if (g->bpp == 3) best_th = 3 * span + 4;
+			/* RGB8: since the tap windows are picked apart by byte alignment (round 3) the kernel holds 181 registers, 8 waves
+			 * per CU, and longer tiles win (tools/ab.py --bpp 3, one allocation: th 25 62.6 %, 33 64.2, 41 65.8, 49 65.8,
+			 * 57 64.6; round 2's kernel, 12 waves per CU, peaked at th 21-25 with 65.1 %) */
+			if (g->bpp == 3) best_th = 6 * span - 1;
 			if (best_th < 24) best_th = 24;
 			if (best_th > 128) best_th = 128;
 		}
@@ -542,13 +543,89 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 	return true;
 }
 
+/* ---- plan for the NONE byte mover on wide samples (fixca_move.hip) --------------------- */
+
+static int move_col_align(int pb) { return (pb % 16 == 0) ? 1 : (pb % 8 == 0) ? 2 : (pb % 4 == 0) ? 4 : 8; }
+
+/* does every strip's window (its own columns for green / alpha, the red and the blue source columns) fit a ring row
+ * of winb bytes that starts on a column the kernel can start it on? */
+static bool move_cols_fit(const FixcaGeom *g, int ocpx, int winb)
+{
+	const int W = g->W, pb = g->bpp, a = move_col_align(pb);
+	for (int X0 = 0; X0 < W; X0 += ocpx) {
+		const int xl = (X0 + ocpx < W ? X0 + ocpx : W) - 1;
+		int lo = X0, hi = xl;
+		for (int c = 0; c < 2; ++c) {
+			/* the map is monotone for s > 0: the strip's first column has the lowest source column, its last the highest */
+			const int f = h_map_int(X0, g->xc, W, g->s[c], g->xs[c]), l = h_map_int(xl, g->xc, W, g->s[c], g->xs[c]);
+			if (f < lo) lo = f;
+			if (l > hi) hi = l;
+		}
+		const int U0 = lo & ~(a - 1);
+		if ((long long)(hi + 1 - U0) * pb > winb) return false;
+	}
+	return true;
+}
+
+static bool plan_move(const FixcaGeom *g, FixcaPlan *pl)
+{
+	if (g->interp != 0 || g->bpc == 1) return false;
+	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
+	const long long pitch = (long long)W * pb;
+	if (pitch % 4) return false;                         /* RGB u16 of odd width: rows are not whole dwords (k_wcol's ODDW path) */
+	const int span = scan_row_span(g, 0);
+	/* a strip is a whole number of 16-byte units AND of pixels: a multiple of `step` columns */
+	const int step = (pb % 16 == 0) ? 1 : (pb % 8 == 0) ? 2 : (pb % 4 == 0) ? 4 : 8;
+	const int nu_env = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
+	/* KiB per ring row: the window is wider than the strip by the red / blue displacement (in pixels), so wide pixels want
+	 * wide rows: 1 KiB for 6-8-byte pixels (RGBA u16: 128 columns), 2 KiB for 12-16, 4 KiB for 24-32; smaller when the ring
+	 * (span + rows in flight) would not fit */
+	int nu = nu_env ? nu_env : (pb <= 8 ? 1 : pb <= 16 ? 2 : 4);
+	if (nu == 3) nu = 2;
+	for (; nu >= 1; nu >>= 1) {
+		int ring = env_int("FIXCA_RING", 0, 0, 64);
+		if (ring == 0) ring = span + MOVE_DEPTH + 1;
+		if (ring < span + 2 || (long long)ring * nu * 1024 > MOVE_LDS_MAX) continue;
+		const int winb = nu * 1024;
+		const int oc_env = env_int("FIXCA_OC", 0, 0, 1 << 20);
+		int oc_top = 64 * nu * 16 / pb / step * step;    /* 64 lanes x nu units */
+		if (oc_env && oc_env < oc_top) oc_top = oc_env / step * step;
+		int oc_pick = 0;
+		for (int oc = oc_top; oc >= step && oc * pb >= winb / 2 && !oc_pick; oc -= step)
+			if (move_cols_fit(g, oc, winb)) oc_pick = oc;
+		if (!oc_pick) continue;
+		pl->kernel = FIXCA_K_MOVE;
+		pl->nu = nu;
+		pl->oc = oc_pick;
+		pl->ring = ring;
+		pl->nstrips = (W + oc_pick - 1) / oc_pick;
+		/* rows per tile: every tile of the image resident at once when that gives tiles of 32 rows or more (a tile's start
+		 * costs a ring fill), else 64-row tiles in several rounds */
+		int per_cu = (160 * 1024) / (ring * winb + 256);
+		if (per_cu > 8) per_cu = 8;
+		if (per_cu < 1) per_cu = 1;
+		const int per_round = per_cu * 256 / pl->nstrips > 0 ? per_cu * 256 / pl->nstrips : 1;
+		int th = (rows + per_round - 1) / per_round;
+		if (th < 32) th = 64;
+		if (th > 512) th = 512;
+		pl->th = env_int("FIXCA_TH", th, 1, 4096);
+		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * pitch > (1LL << 31)) return false;    /* 32-bit offsets into a tile's rows */
+		pl->nchunks = (rows + pl->th - 1) / pl->th;
+		if (pl->nchunks < 1) pl->nchunks = 1;
+		pl->nwaves = pl->nstrips * pl->nchunks;
+		pl->nblocks = (pl->nwaves + 7) & ~7;
+		return true;
+	}
+	return false;
+}
+
 static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl);
 
 /* The planner walks every column and row of the image (tens of microseconds for 6000x4000,
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_MOVE_NU", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH" };
 
 static void env_signature(char *buf, size_t n)
@@ -563,8 +640,8 @@ static void env_signature(char *buf, size_t n)
 
 int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; char env[160]; FixcaPlan pl; } last;
-	char env[160];
+	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; char env[192]; FixcaPlan pl; } last;
+	char env[192];
 	env_signature(env, sizeof env);
 	if (last.valid && last.flags == flags && memcmp(&last.g, g, sizeof *g) == 0 && strcmp(last.env, env) == 0) {
 		*pl = last.pl;
@@ -591,6 +668,8 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		/* 16/32-bit and floating-point samples: the rolling kernel (fp64 for LINEAR / CUBIC, a copy for NONE),
 		 * bit-exact like the one-thread-per-pixel kernel, which stays as the checker and as the fallback
 		 * for scales that drift more than a window over one strip */
+		if (!fixca_debug_flag("FIXCA_NO_MOVE") && plan_move(g, pl)) return FIXCA_OK;
+		memset(pl, 0, sizeof *pl);
 		if (!fixca_debug_flag("FIXCA_NO_WCOL") && plan_wide(g, pl)) return FIXCA_OK;
 		memset(pl, 0, sizeof *pl);
 		pl->kernel = FIXCA_K_EXACT;
@@ -636,7 +715,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n)
 {
-	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "scanw", "roll", "wide-roll-fp64" };
+	static const char *kn[] = { "?", "exact-fp64", "fast-none", "fast-interp", "scan", "(removed)", "roll", "wide-roll-fp64", "move-none" };
 	static const char *in[] = { "none", "linear", "cubic" };
 	if (!buf || !n) return;
 	if (pl->kernel == FIXCA_K_EXACT)
@@ -644,6 +723,9 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 	else if (pl->kernel == FIXCA_K_WCOL)
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
 		         pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->wide_fast ? " weights+recheck" : "");
+	else if (pl->kernel == FIXCA_K_MOVE)
+		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d ring=%dx%dK strips=%d chunks=%d waves=%d", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
+		         pl->oc, pl->th, pl->ring, pl->nu, pl->nstrips, pl->nchunks, pl->nwaves);
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

@@ -188,7 +188,8 @@ def _fuzz_cases(n, seed):
     return cases
 
 
-@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0)], ids=str)
+@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0),
+                                            (4, 4, 0), (-4, 3, 0), (-8, 4, 0), (-8, 3, 0)], ids=str)
 def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
     """k_wcol against the one-thread-per-pixel kernel (itself checked against the oracle above) on BASELINE's
     6000x4000: every tile geometry of a real launch, and enough samples for rare hardware races to show
@@ -203,7 +204,7 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
         raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
-    assert "wide-roll" in fixca.plan(w, h, nch * sb, bpc, p)[1]
+    assert ("move-none" if interp == 0 else "wide-roll") in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
     for _ in range(2):       # twice: the second launch runs against warm caches, other timing
         fixca.fix_ca_region(raw, a, w, h, nch * sb, bpc, p, 0, w, 0, h, True, fixca.KERNEL_AUTO)
@@ -333,6 +334,49 @@ def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
         assert np.all(got[:7] == 0x5A) and np.all(got[h - 3:] == 0x5A)
 
 
+MOVE_PARAMS = [
+    dict(blue=2.0, red=-2.0, lens_x=0.3, lens_y=0.4),                                         # the configs' lateral CA
+    dict(blue=-7.5, red=9.0, lens_x=-1, lens_y=-1, y_blue=11.0, x_red=-13.5),                  # steps inside strips and tiles, large shifts
+    dict(lens_x=0.5, lens_y=0.5, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0),               # directional: pure translation
+    dict(blue=0.4, red=-0.3, lens_x=0.9, lens_y=0.1, x_blue=-3.0, y_red=2.0),
+]
+
+
+@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("nch", [3, 4])
+@pytest.mark.parametrize("shape", [(158, 61), (362, 140), (1202, 77), (244, 300), (2050, 33)], ids=str)
+def test_move_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, shape):
+    """k_move (fixca_move.hip), interpolation NONE on every wide sample type: ring rows of 1, 2 and 4 KiB, strips that
+    end in a partial 16-byte unit (RGB), several strips and tiles, row ranges, scale steps and shifts up to the ring's
+    reach: the bytes the oracle produces (fix-ca.c:1100-1121 copies samples, so any difference is a wrong address)"""
+    torch = torch_cuda
+    w, h = shape
+    sb = abs(bpc)
+    img = _wide_image(dtype, w, h, nch, 2300 + abs(bpc) + w + nch)
+    src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+    took = 0
+    for pi, kw in enumerate(MOVE_PARAMS):
+        p = fixca.make_params(interpolation=0, **_scaled(kw, w, h))
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc).view(np.uint8).reshape(h, w, nch * sb)
+        for nu, th in ((0, 0), (1, 7), (2, 64), (4, 200)):
+            monkeypatch.setenv("FIXCA_MOVE_NU", str(nu))
+            monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
+            kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
+            if pi in (0, 2, 3):
+                assert kid == 8, desc                      # mild geometries must take the mover
+            took += kid == 8
+            dst = torch.full_like(src, 0x3C)
+            fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+            part = torch.full_like(src, 0x5A)
+            fixca.fix_ca_region(src, part, w, h, nch * sb, bpc, p, 0, w, 9, h - 4, True)
+            torch.cuda.synchronize()
+            assert dst.cpu().numpy().tobytes() == ref.tobytes(), (desc, kw)
+            got = part.cpu().numpy()
+            assert got[9:h - 4].tobytes() == ref[9:h - 4].tobytes(), (desc, kw)
+            assert np.all(got[:9] == 0x5A) and np.all(got[h - 4:] == 0x5A)
+    assert took >= 12
+
+
 @pytest.mark.parametrize("idx", range(24))
 def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
     """random geometries and parameters (the 8-bit fuzz set) on the wide sample types: whatever kernel
@@ -362,7 +406,7 @@ def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
         got = dst.cpu().numpy()
         assert got[y1:y2].tobytes() == ref.view(np.uint8).reshape(h, w, nch * sb)[y1:y2].tobytes(), (desc, kw)
         assert np.all(got[:y1] == 0x6B) and np.all(got[y2:] == 0x6B)
-    assert seen <= {1, 7}
+    assert seen <= {1, 7, 8}
 
 
 @pytest.mark.parametrize("nch", [3, 4])
