@@ -82,7 +82,7 @@ def test_plan_refuses_formats_and_domain():
         assert e.value.code == fixca.E_UNSUPPORTED
     for bytes_, bpc in ((8, 2), (6, 2), (16, 4), (16, -4), (12, -4), (32, -8)):     # u16, u32, float, double
         k, desc = fixca.plan(32, 16, bytes_, bpc, p)
-        assert k == (7 if bpc == 2 else 1) and "bpc=%d" % bpc in desc   # NONE: the rolling kernel on 16-bit samples only
+        assert k == 8 and "bpc=%d" % bpc in desc      # NONE (make_params' default): the byte mover on every wide type
         assert fixca.plan(32, 16, bytes_, bpc, fixca.make_params(blue=1, red=-1, lens_x=16, lens_y=8, interpolation=2))[0] == 7
         k, desc = fixca.plan(32, 16, bytes_, bpc, p, kernel=fixca.KERNEL_EXACT)
         assert k == 1 and "bpc=%d" % bpc in desc                     # the one-thread-per-pixel fp64 kernel
