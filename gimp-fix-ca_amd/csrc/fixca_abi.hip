@@ -22,9 +22,11 @@ extern "C" hipError_t fixca_launch_preview(const void *, void *, int, int, int, 
 extern "C" hipError_t fixca_launch_centerline(void *, const FixcaGeom *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_roll_batch_rgb(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_move_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+#include "fixca_move.h"
 
 /* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (128) per launch, the
- * other kernels one */
+ * NONE mover of the wide sample types up to MOVE_BATCH_MAX (32), the other kernels one */
 static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
                        hipStream_t stream, int *launches);
 
@@ -172,6 +174,12 @@ static int launch_many(const void *const *d_src, void *const *d_dst, int n, cons
 			const int m = n - i < ROLL_BATCH_MAX ? n - i : ROLL_BATCH_MAX;
 			if (g->bpp == 3) HIP_TRY(fixca_launch_roll_batch_rgb(d_src + i, d_dst + i, m, g, pl, stream));
 			else             HIP_TRY(fixca_launch_roll_batch(d_src + i, d_dst + i, m, g, pl, stream));
+			++count;
+		}
+	} else if (pl->kernel == FIXCA_K_MOVE && g->y2 > g->y1) {
+		for (int i = 0; i < n; i += MOVE_BATCH_MAX) {
+			const int m = n - i < MOVE_BATCH_MAX ? n - i : MOVE_BATCH_MAX;
+			HIP_TRY(fixca_launch_move_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			++count;
 		}
 	} else {

@@ -36,6 +36,7 @@ struct FixcaPlan {
 	                       for kernels 2,3; one 64-thread wave for kernel 4)  */
 	int ring;           /* kernels 4, 6, 8: source rows in the LDS ring         */
 	int nu;             /* kernel 8: KiB per ring row = 16-byte units a lane moves per output row (1, 2, 4) */
+	int depth;          /* kernel 8: source rows kept in flight beyond the newest row in use */
 	int wide_fast;      /* kernel 7, 16-bit samples, CUBIC: the weight form with exact recomputation of the
 	                       samples near a rounding boundary (fixca_wide.hip); 0 = operation for operation */
 };

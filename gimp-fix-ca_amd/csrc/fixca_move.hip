@@ -22,7 +22,9 @@
  *            LDS reads from the red / blue source row;
  *      RGB:  units straddle pixels (16 is not a multiple of 6, 12 or 24), the channel of sample k of a unit depends on
  *            the unit modulo 3: every sample is gathered, from the row its channel calls for.
- *  - counted s_waitcnt vmcnt on the loads alone, rows prefetched MOVE_DEPTH ahead, as in k_roll.
+ *  - counted s_waitcnt vmcnt on the loads alone, rows prefetched `depth` ahead, as in k_roll; output rows go in
+ *    blocks of RB (RB x NU = 4 units per lane): all LDS reads of a block are issued before the first is used.
+ *  - a launch takes up to MOVE_BATCH_MAX images of one geometry (fixca_batch_device).
  *
  * The planner (plan_move, fixca_plan.cpp) takes a geometry when every strip's window (identity columns + red and
  * blue source columns) fits a ring row and rows are a whole number of dwords; everything else stays with
@@ -58,7 +60,7 @@ __host__ __device__ constexpr int move_col_align(int pb)
 
 template <int SB, int NCH, int NU>     /* SB: bytes per sample (2, 4, 8); NCH: samples per pixel; NU: KiB per ring row */
 __global__ __launch_bounds__(64) void
-k_move(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, MovePlan mp)
+k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
 	constexpr int PB = SB * NCH;                       /* bytes per pixel                               */
@@ -68,8 +70,14 @@ k_move(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 
 	const int lane = threadIdx.x;
 	const int W = g.W, H = g.H;
-	const int tile = xcd_remap(blockIdx.x, mp.nblocks);
+	/* a launch covers n independent images of one geometry: image k's tiles are workgroups [k nblocks, (k + 1) nblocks),
+	 * handed out in order, so image k + 1's first waves start in the slots image k's last waves leave */
+	const int img = blockIdx.x / mp.nblocks;
+	const int tile = xcd_remap(blockIdx.x - img * mp.nblocks, mp.nblocks);
 	if (tile >= mp.nwaves) return;
+	const uint8_t *__restrict__ src = imgs.src[img];
+	uint8_t *__restrict__ dst = imgs.dst[img];
+	constexpr int RB = MOVE_RB(NU);                    /* output rows per block                         */
 	const int strip = tile % mp.nstrips, chunk = tile / mp.nstrips;
 	const int X0 = strip * mp.ocpx, xe = min(X0 + mp.ocpx, W);
 	const int Y0 = g.y1 + chunk * mp.th;
@@ -159,10 +167,13 @@ k_move(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	 * loads and stores; the wait relies on the loads alone (rows are loaded in order, NU loads each): stores in flight
 	 * make it stricter, never wrong (fixca_roll.hip, roll_fetch) */
 	auto fetch = [&](int keep, int need) {
-		const int target = min(min(need + MOVE_DEPTH, keep + K - 1), lastneed_s);
+		const int target = min(min(need + mp.depth, keep + K - 1), lastneed_s);
 		while (ld < target) issue();
 		const int younger = ld - need;
-		if (younger >= 6) move_wait_vm<6 * NU>();
+		if (younger >= 12) move_wait_vm<12 * NU>();                              /* vmcnt holds 6 bits: 12 x 4 = 48 */
+		else if (younger >= 10) move_wait_vm<10 * NU>();
+		else if (younger >= 8) move_wait_vm<8 * NU>();
+		else if (younger >= 6) move_wait_vm<6 * NU>();
 		else if (younger >= 4) move_wait_vm<4 * NU>();
 		else if (younger >= 3) move_wait_vm<3 * NU>();
 		else if (younger >= 2) move_wait_vm<2 * NU>();
@@ -171,82 +182,97 @@ k_move(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, FixcaGeom g, 
 	};
 
 	uint32_t so_st = 0;
-	for (int r = 0; r < nrows; ++r) {
+	for (int r = 0; r < nrows; r += RB) {
 		if (r && (r & 63) == 0) row_tables(r);
-		const int y = Y0 + r;
-		const int rR = __builtin_amdgcn_readlane(rowR_v, r & 63), rB = __builtin_amdgcn_readlane(rowB_v, r & 63);
-		const int keep = min(y, min(rR, rB)), need = max(y, max(rR, rB));
-		/* every LDS read of the previous row has returned (its stores consumed them): the slots below `keep` are free */
-		fetch(keep, need);
-		const uint32_t bI = (uint32_t)move_slot(y, K, kmagic) * WINB, bR = (uint32_t)move_slot(rR, K, kmagic) * WINB,
-		               bB = (uint32_t)move_slot(rB, K, kmagic) * WINB;
-		u32x4 out[NU];
+		/* the block's rows; rows past the tile repeat its last row (their stores go nowhere) */
+		int yy[RB], rR[RB], rB[RB];
 #pragma unroll
-		for (int i = 0; i < NU; ++i) {
-			if constexpr (NCH == 4) {
-				u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
-				if constexpr (SB == 2) {
-					const uint32_t r0 = *reinterpret_cast<const uint16_t *>(ring + bR + goff[i][0]);
-					const uint32_t b0 = *reinterpret_cast<const uint16_t *>(ring + bB + goff[i][1]);
-					const uint32_t r1 = *reinterpret_cast<const uint16_t *>(ring + bR + goff[i][2]);
-					const uint32_t b1 = *reinterpret_cast<const uint16_t *>(ring + bB + goff[i][3]);
-					v.x = (v.x & 0xFFFF0000u) | r0; v.y = (v.y & 0xFFFF0000u) | b0;
-					v.z = (v.z & 0xFFFF0000u) | r1; v.w = (v.w & 0xFFFF0000u) | b1;
-				} else if constexpr (SB == 4) {
-					v.x = *reinterpret_cast<const uint32_t *>(ring + bR + goff[i][0]);
-					v.z = *reinterpret_cast<const uint32_t *>(ring + bB + goff[i][1]);
-				} else {
-					const u32x2 s = *reinterpret_cast<const u32x2 *>(ring + (chsel[i] ? bB : bR) + goff[i][0]);
-					v.x = s.x; v.y = s.y;
-				}
-				out[i] = v;
-			} else {
-				/* channel of sample k: (chsel + k) mod 3; its row: red's, this one, blue's */
-				uint32_t base[3];
+		for (int j = 0; j < RB; ++j) {
+			const int rj = min(r + j, nrows - 1);
+			yy[j] = Y0 + rj;
+			rR[j] = __builtin_amdgcn_readlane(rowR_v, rj & 63);
+			rB[j] = __builtin_amdgcn_readlane(rowB_v, rj & 63);
+		}
+		/* the maps are monotone: the block's oldest row is its first row's, its newest its last row's.
+		 * Every LDS read of the previous block has returned (its stores consumed them): the slots below `keep` are free */
+		fetch(min(yy[0], min(rR[0], rB[0])), max(yy[RB - 1], max(rR[RB - 1], rB[RB - 1])));
+		u32x4 out[RB][NU];
 #pragma unroll
-				for (int j = 0; j < 3; ++j) {
-					const int c = (chsel[i] + j) % 3;
-					base[j] = (c == 0) ? bR : (c == 2) ? bB : bI;
-				}
-				uint32_t w[4];
-				if constexpr (SB == 2) {
+		for (int j = 0; j < RB; ++j) {
+			const uint32_t bI = (uint32_t)move_slot(yy[j], K, kmagic) * WINB, bR = (uint32_t)move_slot(rR[j], K, kmagic) * WINB,
+			               bB = (uint32_t)move_slot(rB[j], K, kmagic) * WINB;
 #pragma unroll
-					for (int d = 0; d < 4; ++d) {
-						const uint32_t a = *reinterpret_cast<const uint16_t *>(ring + base[(2 * d) % 3] + goff[i][2 * d]);
-						const uint32_t b = *reinterpret_cast<const uint16_t *>(ring + base[(2 * d + 1) % 3] + goff[i][2 * d + 1]);
-						w[d] = a | (b << 16);
+			for (int i = 0; i < NU; ++i) {
+				if constexpr (NCH == 4) {
+					u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
+					if constexpr (SB == 2) {
+						const uint32_t r0 = *reinterpret_cast<const uint16_t *>(ring + bR + goff[i][0]);
+						const uint32_t b0 = *reinterpret_cast<const uint16_t *>(ring + bB + goff[i][1]);
+						const uint32_t r1 = *reinterpret_cast<const uint16_t *>(ring + bR + goff[i][2]);
+						const uint32_t b1 = *reinterpret_cast<const uint16_t *>(ring + bB + goff[i][3]);
+						v.x = (v.x & 0xFFFF0000u) | r0; v.y = (v.y & 0xFFFF0000u) | b0;
+						v.z = (v.z & 0xFFFF0000u) | r1; v.w = (v.w & 0xFFFF0000u) | b1;
+					} else if constexpr (SB == 4) {
+						v.x = *reinterpret_cast<const uint32_t *>(ring + bR + goff[i][0]);
+						v.z = *reinterpret_cast<const uint32_t *>(ring + bB + goff[i][1]);
+					} else {
+						const u32x2 s = *reinterpret_cast<const u32x2 *>(ring + (chsel[i] ? bB : bR) + goff[i][0]);
+						v.x = s.x; v.y = s.y;
 					}
-				} else if constexpr (SB == 4) {
-#pragma unroll
-					for (int d = 0; d < 4; ++d) w[d] = *reinterpret_cast<const uint32_t *>(ring + base[d % 3] + goff[i][d]);
+					out[j][i] = v;
 				} else {
+					/* channel of sample k: (chsel + k) mod 3; its row: red's, this one, blue's */
+					uint32_t base[3];
 #pragma unroll
-					for (int d = 0; d < 2; ++d) {
-						const u32x2 s = *reinterpret_cast<const u32x2 *>(ring + base[d] + goff[i][d]);
-						w[2 * d] = s.x; w[2 * d + 1] = s.y;
+					for (int q = 0; q < 3; ++q) {
+						const int c = (chsel[i] + q) % 3;
+						base[q] = (c == 0) ? bR : (c == 2) ? bB : bI;
 					}
+					uint32_t w[4];
+					if constexpr (SB == 2) {
+#pragma unroll
+						for (int d = 0; d < 4; ++d) {
+							const uint32_t a = *reinterpret_cast<const uint16_t *>(ring + base[(2 * d) % 3] + goff[i][2 * d]);
+							const uint32_t b = *reinterpret_cast<const uint16_t *>(ring + base[(2 * d + 1) % 3] + goff[i][2 * d + 1]);
+							w[d] = a | (b << 16);
+						}
+					} else if constexpr (SB == 4) {
+#pragma unroll
+						for (int d = 0; d < 4; ++d) w[d] = *reinterpret_cast<const uint32_t *>(ring + base[d % 3] + goff[i][d]);
+					} else {
+#pragma unroll
+						for (int d = 0; d < 2; ++d) {
+							const u32x2 s = *reinterpret_cast<const u32x2 *>(ring + base[d] + goff[i][d]);
+							w[2 * d] = s.x; w[2 * d + 1] = s.y;
+						}
+					}
+					out[j][i] = u32x4{ w[0], w[1], w[2], w[3] };
 				}
-				out[i] = u32x4{ w[0], w[1], w[2], w[3] };
 			}
 		}
 		/* The row offset goes into the vector offset, the scalar offset stays the constant 0: with a register there the
 		 * compiler leaves no wait state between a 16-byte store and the next write of its data registers, and on MI355X the
 		 * store then carries the next row's bytes ("a hardware hazard"; tests/test_host_logic.py scans for it) */
 #pragma unroll
-		for (int i = 0; i < NU; ++i)
-			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);
-		if (tail_dw) {                                  /* wave-uniform: a strip whose row does not end on a unit boundary */
+		for (int j = 0; j < RB; ++j) {
+			const bool live = r + j < nrows;                /* wave-uniform */
 #pragma unroll
 			for (int i = 0; i < NU; ++i)
-				if (i == tail_u) {
-					const uint32_t o = (lane == tail_lane) ? (uint32_t)(X0 * PB + 16 * (lane + 64 * i)) + so_st : dst_bytes;
+				__builtin_amdgcn_raw_buffer_store_b128(out[j][i], rs_dst, live ? stoff[i] + so_st : dst_bytes, 0, 2);
+			if (tail_dw) {                                  /* wave-uniform: a strip whose row does not end on a unit boundary */
 #pragma unroll
-					for (int d = 0; d < 3; ++d)
-						if (d < tail_dw) __builtin_amdgcn_raw_buffer_store_b32(out[i][d], rs_dst, o == dst_bytes ? dst_bytes : o + 4 * d, 0, 2);
-				}
+				for (int i = 0; i < NU; ++i)
+					if (i == tail_u) {
+						const bool mine = live && lane == tail_lane;
+						const uint32_t o = (uint32_t)(X0 * PB + 16 * (lane + 64 * i)) + so_st;
+#pragma unroll
+						for (int d = 0; d < 3; ++d)
+							if (d < tail_dw) __builtin_amdgcn_raw_buffer_store_b32(out[j][i][d], rs_dst, mine ? o + 4 * d : dst_bytes, 0, 2);
+					}
+			}
+			so_st += pitch;
 		}
-		so_st += pitch;
-		/* the next iteration overwrites ring slots: every LDS read above must have returned.  The stores consume the
+		/* the next block overwrites ring slots: every LDS read above must have returned.  The stores consume the
 		 * data, so the compiler has waited already; the explicit wait costs nothing and does not depend on that */
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	}
@@ -280,14 +306,15 @@ const void *move_kernel_for(const FixcaGeom *g, int nu)
 }   /* namespace */
 
 extern "C" hipError_t
-fixca_launch_move(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+fixca_launch_move_batch(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
 	if (g->y2 <= g->y1) return hipSuccess;
-	if (g->interp != 0 || (pl->nu != 1 && pl->nu != 2 && pl->nu != 4)) return hipErrorInvalidValue;
+	if (n_images < 1 || n_images > MOVE_BATCH_MAX) return hipErrorInvalidValue;
+	if (g->interp != 0 || (pl->nu != 1 && pl->nu != 2 && pl->nu != 4) || pl->depth < 1 || pl->depth > MOVE_DEPTH_MAX) return hipErrorInvalidValue;
 	const void *fn = move_kernel_for(g, pl->nu);
 	if (!fn) return hipErrorInvalidValue;
-	const size_t lds = (size_t)pl->ring * pl->nu * 1024;
-	if (lds > MOVE_LDS_MAX) return hipErrorInvalidValue;
+	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + 64;      /* + a pad: the 16-byte read of a strip's last, partial unit may end past the last ring row */
+	if (lds > MOVE_LDS_MAX + 64) return hipErrorInvalidValue;
 	/* dynamic LDS above the default limit needs the attribute once per function */
 	static std::mutex mu;
 	static const void *done[32];
@@ -297,15 +324,24 @@ fixca_launch_move(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 		bool seen = false;
 		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
 		if (!seen) {
-			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX);
+			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + 64);
 			if (ndone < 32) done[ndone++] = fn;
 		}
 	}
 	MovePlan mp;
-	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
-	const uint8_t *s = static_cast<const uint8_t *>(d_src);
-	uint8_t *d = static_cast<uint8_t *>(d_dst);
+	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.depth = pl->depth; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
+	MoveBatch imgs;
+	for (int i = 0; i < MOVE_BATCH_MAX; ++i) {
+		imgs.src[i] = static_cast<const unsigned char *>(d_src[i < n_images ? i : 0]);
+		imgs.dst[i] = static_cast<unsigned char *>(d_dst[i < n_images ? i : 0]);
+	}
 	FixcaGeom geom = *g;
-	void *args[] = { &s, &d, &geom, &mp };
-	return hipLaunchKernel(fn, dim3((unsigned)mp.nblocks), dim3(64), args, lds, stream);
+	void *args[] = { &imgs, &geom, &mp };
+	return hipLaunchKernel(fn, dim3((unsigned)mp.nblocks * (unsigned)n_images), dim3(64), args, lds, stream);
+}
+
+extern "C" hipError_t
+fixca_launch_move(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+{
+	return fixca_launch_move_batch(&d_src, &d_dst, 1, g, pl, stream);
 }

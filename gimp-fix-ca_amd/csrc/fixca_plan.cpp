@@ -567,26 +567,39 @@ static bool move_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 	return true;
 }
 
-static bool plan_move(const FixcaGeom *g, FixcaPlan *pl)
+static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
 	if (g->interp != 0 || g->bpc == 1) return false;
 	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
 	const long long pitch = (long long)W * pb;
 	if (pitch % 4) return false;                         /* RGB u16 of odd width: rows are not whole dwords (k_wcol's ODDW path) */
 	const int span = scan_row_span(g, 0);
+	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
 	/* a strip is a whole number of 16-byte units AND of pixels: a multiple of `step` columns */
 	const int step = (pb % 16 == 0) ? 1 : (pb % 8 == 0) ? 2 : (pb % 4 == 0) ? 4 : 8;
+	/* Shape of a launch, measured on MI355X with 6000x4000 images (tools/sweep_move.sh, one allocation per format):
+	 *   one image per launch: about two waves per CU, each streaming a tall column with ~14 KiB of loads in flight, beats
+	 *     every wider or shorter tiling: RGBA float 1-KiB ring rows (64 columns), 800-row tiles, 14 rows in flight 74.6 %
+	 *     of the HBM peak (6 in flight, 112-row tiles: 64.0 %); RGBA double 2-KiB rows, 800-row tiles 74.6 % (4-KiB rows,
+	 *     267-row tiles: 66.1 %).  16-bit samples cost a wave more LDS time per byte (a 2-byte gather per sample, 4-way
+	 *     bank conflicts at a 16-byte lane stride): three waves per CU, 63.7 %.
+	 *   many images per launch (fixca_batch_device): the GPU is full whatever the tiling; short tiles of wide rows,
+	 *     10 rows in flight: u16 4-KiB rows x 64 rows 70.3 %, float 2 KiB x 32 72.7 %, double 2 KiB x 32 74.1 %. */
 	const int nu_env = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	/* KiB per ring row: the window is wider than the strip by the red / blue displacement (in pixels), so wide pixels want
-	 * wide rows: 1 KiB for 6-8-byte pixels (RGBA u16: 128 columns), 2 KiB for 12-16, 4 KiB for 24-32; smaller when the ring
-	 * (span + rows in flight) would not fit */
-	int nu = nu_env ? nu_env : (pb <= 8 ? 1 : pb <= 16 ? 2 : 4);
+	int nu = nu_env ? nu_env : batch ? (pb <= 8 ? 4 : 2) : (pb <= 16 ? 1 : 2);
 	if (nu == 3) nu = 2;
 	for (; nu >= 1; nu >>= 1) {
-		int ring = env_int("FIXCA_RING", 0, 0, 64);
-		if (ring == 0) ring = span + MOVE_DEPTH + 1;
-		if (ring < span + 2 || (long long)ring * nu * 1024 > MOVE_LDS_MAX) continue;
+		const int rb = MOVE_RB(nu);                      /* a block of rb output rows keeps span + rb - 1 source rows alive */
 		const int winb = nu * 1024;
+		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
+		if (depth == 0) depth = batch ? 10 : (14 * 1024 + winb - 1) / winb;
+		if (depth < 2) depth = 2;
+		int ring = env_int("FIXCA_RING", 0, 0, 96);
+		if (ring == 0) {
+			ring = span + rb - 1 + depth + 1;
+			while ((long long)ring * winb > MOVE_LDS_MAX && depth > 2) { --depth; --ring; }     /* large shifts: fewer rows in flight */
+		}
+		if (ring < span + rb + 1 || (long long)ring * winb > MOVE_LDS_MAX) continue;
 		const int oc_env = env_int("FIXCA_OC", 0, 0, 1 << 20);
 		int oc_top = 64 * nu * 16 / pb / step * step;    /* 64 lanes x nu units */
 		if (oc_env && oc_env < oc_top) oc_top = oc_env / step * step;
@@ -596,23 +609,31 @@ static bool plan_move(const FixcaGeom *g, FixcaPlan *pl)
 		if (!oc_pick) continue;
 		pl->kernel = FIXCA_K_MOVE;
 		pl->nu = nu;
+		pl->depth = depth;
 		pl->oc = oc_pick;
 		pl->ring = ring;
 		pl->nstrips = (W + oc_pick - 1) / oc_pick;
-		/* rows per tile: every tile of the image resident at once when that gives tiles of 32 rows or more (a tile's start
-		 * costs a ring fill), else 64-row tiles in several rounds */
-		int per_cu = (160 * 1024) / (ring * winb + 256);
-		if (per_cu > 8) per_cu = 8;
-		if (per_cu < 1) per_cu = 1;
-		const int per_round = per_cu * 256 / pl->nstrips > 0 ? per_cu * 256 / pl->nstrips : 1;
-		int th = (rows + per_round - 1) / per_round;
-		if (th < 32) th = 64;
-		if (th > 512) th = 512;
+		int th;
+		if (batch) {
+			th = (nu == 4 && pb <= 8) ? 64 : 32;
+		} else {
+			const int want = (pb <= 8) ? 768 : 512;          /* waves of the launch */
+			int chunks = (want + pl->nstrips / 2) / pl->nstrips;
+			if (chunks < 1) chunks = 1;
+			th = (rows + chunks - 1) / chunks;
+			if (th < 32) th = 32;
+		}
 		pl->th = env_int("FIXCA_TH", th, 1, 4096);
-		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * pitch > (1LL << 31)) return false;    /* 32-bit offsets into a tile's rows */
+		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * pitch > (1LL << 31)) {
+			/* 32-bit offsets into a tile's rows: shorter tiles for very wide images */
+			const long long fit = (1LL << 31) / pitch - 2 * FIXCA_SOURCE_ROWS;
+			if (fit < 8) return false;
+			pl->th = (int)fit;
+		}
 		pl->nchunks = (rows + pl->th - 1) / pl->th;
 		if (pl->nchunks < 1) pl->nchunks = 1;
 		pl->nwaves = pl->nstrips * pl->nchunks;
+		if ((long long)pl->nwaves + 8 > (1LL << 31) / MOVE_BATCH_MAX) return false;
 		pl->nblocks = (pl->nwaves + 7) & ~7;
 		return true;
 	}
@@ -625,7 +646,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_MOVE_NU", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_MOVE_NU", "FIXCA_MOVE_DEPTH", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH" };
 
 static void env_signature(char *buf, size_t n)
@@ -640,8 +661,8 @@ static void env_signature(char *buf, size_t n)
 
 int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; char env[192]; FixcaPlan pl; } last;
-	char env[192];
+	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; char env[224]; FixcaPlan pl; } last;
+	char env[224];
 	env_signature(env, sizeof env);
 	if (last.valid && last.flags == flags && memcmp(&last.g, g, sizeof *g) == 0 && strcmp(last.env, env) == 0) {
 		*pl = last.pl;
@@ -668,7 +689,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		/* 16/32-bit and floating-point samples: the rolling kernel (fp64 for LINEAR / CUBIC, a copy for NONE),
 		 * bit-exact like the one-thread-per-pixel kernel, which stays as the checker and as the fallback
 		 * for scales that drift more than a window over one strip */
-		if (!fixca_debug_flag("FIXCA_NO_MOVE") && plan_move(g, pl)) return FIXCA_OK;
+		if (!fixca_debug_flag("FIXCA_NO_MOVE") && plan_move(g, flags, pl)) return FIXCA_OK;
 		memset(pl, 0, sizeof *pl);
 		if (!fixca_debug_flag("FIXCA_NO_WCOL") && plan_wide(g, pl)) return FIXCA_OK;
 		memset(pl, 0, sizeof *pl);
@@ -724,8 +745,8 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
 		         pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->wide_fast ? " weights+recheck" : "");
 	else if (pl->kernel == FIXCA_K_MOVE)
-		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d ring=%dx%dK strips=%d chunks=%d waves=%d", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
-		         pl->oc, pl->th, pl->ring, pl->nu, pl->nstrips, pl->nchunks, pl->nwaves);
+		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d ring=%dx%dK depth=%d strips=%d chunks=%d waves=%d", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
+		         pl->oc, pl->th, pl->ring, pl->nu, pl->depth, pl->nstrips, pl->nchunks, pl->nwaves);
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

@@ -33,7 +33,8 @@ ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--width", type=int, default=6000)
 ap.add_argument("--height", type=int, default=4000)
 ap.add_argument("--single", action="store_true", help="one image per launch through fixca_region_device")
-ap.add_argument("variants", nargs="+")
+ap.add_argument("--grid", default="", help="cartesian product of variants: 'lib=HEAD,d10;FIXCA_TH=0,64,160;per=8' (0 / HEAD = unset / in-tree library)")
+ap.add_argument("variants", nargs="*")
 a = ap.parse_args()
 W, H, N = a.width, a.height, a.images
 SB = abs(a.bpc)
@@ -50,8 +51,22 @@ def parse(v):
             per = int(val)
         else:
             env[k] = val
-    return v, fixca.LIB_PATH if lib is None else os.path.join(BIN, lib, "libfixca_hip.so"), env, per
-VARIANTS = [parse(v) for v in a.variants]
+    return v.replace("FIXCA_", ""), fixca.LIB_PATH if lib is None else os.path.join(BIN, lib, "libfixca_hip.so"), env, per
+def grid(spec):
+    import itertools
+    axes = [ax.split("=", 1) for ax in spec.split(";") if ax]
+    out = []
+    for combo in itertools.product(*[vals.split(",") for _, vals in axes]):
+        lib = ""
+        parts = []
+        for (k, _), v in zip(axes, combo):
+            if k == "lib":
+                lib = "" if v == "HEAD" else "@" + v
+            elif v != "0" or k == "per":
+                parts.append("%s=%s" % (k, v))
+        out.append(",".join(["g" + lib] + parts))
+    return out
+VARIANTS = [parse(v) for v in a.variants + (grid(a.grid) if a.grid else [])]
 
 libs = {}
 def lib_for(path):
