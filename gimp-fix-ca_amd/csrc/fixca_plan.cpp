@@ -583,10 +583,11 @@ static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 *     of the HBM peak (6 in flight, 112-row tiles: 64.0 %); RGBA double 2-KiB rows, 800-row tiles 74.6 % (4-KiB rows,
 	 *     267-row tiles: 66.1 %).  16-bit samples cost a wave more LDS time per byte (a 2-byte gather per sample, 4-way
 	 *     bank conflicts at a 16-byte lane stride): three waves per CU, 63.7 %.
-	 *   many images per launch (fixca_batch_device): the GPU is full whatever the tiling; short tiles of wide rows,
-	 *     10 rows in flight: u16 4-KiB rows x 64 rows 70.3 %, float 2 KiB x 32 72.7 %, double 2 KiB x 32 74.1 %. */
+	 *   many images per launch (fixca_batch_device): the GPU is full whatever the tiling; 32-row tiles of 2-KiB rows,
+	 *     10 rows in flight: u16 65-70 %, float 72.7-73.4 %, double 69.6-74.1 %, RGB u16 63 %, RGB float 65 %, RGB double
+	 *     70 % (two boxes; 4-KiB rows lose 9 points on RGB u16, 1-KiB rows 8 on RGB double). */
 	const int nu_env = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	int nu = nu_env ? nu_env : batch ? (pb <= 8 ? 4 : 2) : (pb <= 16 ? 1 : 2);
+	int nu = nu_env ? nu_env : batch ? 2 : (pb <= 16 ? 1 : 2);
 	if (nu == 3) nu = 2;
 	for (; nu >= 1; nu >>= 1) {
 		const int rb = MOVE_RB(nu);                      /* a block of rb output rows keeps span + rb - 1 source rows alive */
@@ -615,9 +616,12 @@ static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		pl->nstrips = (W + oc_pick - 1) / oc_pick;
 		int th;
 		if (batch) {
-			th = (nu == 4 && pb <= 8) ? 64 : 32;
+			th = 32;
 		} else {
-			const int want = (pb <= 8) ? 768 : 512;          /* waves of the launch */
+			/* waves of the launch: two per CU for RGBA pixels of 16 and 32 bytes (one 16-byte read and one or two gathers per
+			 * unit); formats that gather every sample (RGB) or pay bank conflicts (16-bit) need more waves to hide a wave's
+			 * LDS time: four per CU */
+			const int want = (g->nch == 4 && pb >= 16) ? 512 : 1024;
 			int chunks = (want + pl->nstrips / 2) / pl->nstrips;
 			if (chunks < 1) chunks = 1;
 			th = (rows + chunks - 1) / chunks;
