@@ -2,6 +2,9 @@
  * fixca_plan.cpp — host-side argument validation, geometry and launch planning.
  * No HIP calls here: this file also runs on a machine without a GPU (the
  * planner is exported through fixca_plan_describe and unit-tested on CPU).
+ * One exception, through fixca_wide.hip: LINEAR / CUBIC on the wide sample types ask the
+ * runtime for the current device and its occupancy (fixca_wide_device, fixca_wide_slots);
+ * without a device they plan for a 256-CU part.
  *
  * Compiled with -ffp-contract=off: the coordinate arithmetic below must round
  * exactly like the kernels' (and the reference's) un-fused double expression.
@@ -587,13 +590,14 @@ static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 *     10 rows in flight: u16 65-70 %, float 72.7-73.4 %, double 69.6-74.1 %, RGB u16 63 %, RGB float 65 %, RGB double
 	 *     70 % (two boxes; 4-KiB rows lose 9 points on RGB u16, 1-KiB rows 8 on RGB double). */
 	const int nu_env = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	int nu = nu_env ? nu_env : batch ? 2 : (pb <= 16 ? 1 : 2);
+	const bool light = g->nch == 4 && pb >= 16;          /* one 16-byte read and one or two gathers per unit: a wave streams at full speed */
+	int nu = nu_env ? nu_env : batch ? 2 : (pb <= 8 || pb == 16) ? 1 : 2;
 	if (nu == 3) nu = 2;
 	for (; nu >= 1; nu >>= 1) {
 		const int rb = MOVE_RB(nu);                      /* a block of rb output rows keeps span + rb - 1 source rows alive */
 		const int winb = nu * 1024;
 		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
-		if (depth == 0) depth = batch ? 10 : (14 * 1024 + winb - 1) / winb;
+		if (depth == 0) depth = batch ? 10 : light ? (14 * 1024 + winb - 1) / winb : 6;
 		if (depth < 2) depth = 2;
 		int ring = env_int("FIXCA_RING", 0, 0, 96);
 		if (ring == 0) {
@@ -618,10 +622,11 @@ static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		if (batch) {
 			th = 32;
 		} else {
-			/* waves of the launch: two per CU for RGBA pixels of 16 and 32 bytes (one 16-byte read and one or two gathers per
-			 * unit); formats that gather every sample (RGB) or pay bank conflicts (16-bit) need more waves to hide a wave's
-			 * LDS time: four per CU */
-			const int want = (g->nch == 4 && pb >= 16) ? 512 : 1024;
+			/* waves of the launch: two per CU for RGBA pixels of 16 and 32 bytes; formats that gather every sample (RGB) or
+			 * two-byte samples need more waves to hide a wave's LDS time: three to four per CU, 6 rows in flight
+			 * (one box, tools/sweep_r3g.sh: RGB u16 950 waves 58.5 %, RGB float 925 waves 60.5 %, RGB double 750 waves 69.3 %,
+			 * RGBA u16 flat at 56-57 % from 735 to 3087 waves; the nt copy of the same buffers: 65-73 %) */
+			const int want = light ? 512 : 900;
 			int chunks = (want + pl->nstrips / 2) / pl->nstrips;
 			if (chunks < 1) chunks = 1;
 			th = (rows + chunks - 1) / chunks;
@@ -665,10 +670,14 @@ static void env_signature(char *buf, size_t n)
 
 int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; char env[224]; FixcaPlan pl; } last;
+	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; int device; char env[224]; FixcaPlan pl; } last;
 	char env[224];
 	env_signature(env, sizeof env);
-	if (last.valid && last.flags == flags && memcmp(&last.g, g, sizeof *g) == 0 && strcmp(last.env, env) == 0) {
+	/* k_wcol's tile height is sized to the occupancy the CURRENT device reports (fixca_wide_slots): after
+	 * fixca_set_device() the plan of the previous device must not be handed out.  Only the wide LINEAR / CUBIC plans
+	 * depend on the device; the 8-bit path never touches the HIP runtime here. */
+	const int device = (g->bpc != 1 && g->interp != 0) ? fixca_wide_device() : -1;
+	if (last.valid && last.flags == flags && last.device == device && memcmp(&last.g, g, sizeof *g) == 0 && strcmp(last.env, env) == 0) {
 		*pl = last.pl;
 		return FIXCA_OK;
 	}
@@ -677,6 +686,7 @@ int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		last.valid = true;
 		last.g = *g;
 		last.flags = flags;
+		last.device = device;
 		memcpy(last.env, env, sizeof env);
 		last.pl = *pl;
 	}

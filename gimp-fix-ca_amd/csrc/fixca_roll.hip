@@ -841,70 +841,127 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 /* ---- table cache + launch -------------------------------------------------------------------- */
 
 namespace {
-/* Tables live in device memory and are read by kernels that may still be running when the
- * next call arrives, so a geometry keeps its own buffer: a small per-thread cache of entries.
- * An entry is rebuilt (another geometry evicts it) only after the device has gone idle. */
+/* Tables live in device memory and are read by kernels that may still be running when the next call arrives, so a
+ * geometry keeps its own buffer: a small per-thread cache of entries, least recently used first out.  An entry
+ * remembers its last use with an event recorded behind the kernel that read it; evicting it waits for THAT event only
+ * (an interactive preview that drags a slider brings a new parameter block per call: after 8 calls every call evicts,
+ * and must not pay a device-wide synchronisation for it).  An entry used inside a stream capture is pinned: the graph
+ * may replay the launch at any time, so its tables are never rebuilt (fixca_release_cache() frees them). */
 struct TableEntry {
 	bool        valid = false;
+	bool        pinned = false;             /* read by a captured launch: never evicted */
+	bool        used = false;               /* last_use has been recorded at least once */
 	int         device = -1;
-	FixcaGeom   g;                  /* y1, y2 zeroed: the tables do not depend on the row range */
+	FixcaGeom   g;                          /* the fields the tables depend on (same_tables) */
 	int         oc = 0;
 	void       *mem = nullptr;
 	size_t      bytes = 0;
 	RollTables  tb;
-	hipStream_t built_on = nullptr;
-	hipEvent_t  ready = nullptr;
-	unsigned long long used = 0;
+	hipEvent_t  ready = nullptr;            /* behind the table kernel */
+	hipEvent_t  last_use = nullptr;         /* behind the last k_roll launch that read the tables */
+	hipStream_t last_stream = nullptr;
+	unsigned long long tick = 0;
 };
 constexpr int TABLE_ENTRIES = 8;
 thread_local TableEntry g_tc[TABLE_ENTRIES];
 thread_local unsigned long long g_tick = 0;
+
+/* the tables depend on these fields and on nothing else (not on the row range, not on the preview flag) */
+bool same_tables(const FixcaGeom &a, const FixcaGeom &b)
+{
+	return a.W == b.W && a.H == b.H && a.bpp == b.bpp && a.bpc == b.bpc && a.nch == b.nch && a.xc == b.xc && a.yc == b.yc &&
+	       a.interp == b.interp && a.s[0] == b.s[0] && a.s[1] == b.s[1] && a.xs[0] == b.xs[0] && a.xs[1] == b.xs[1] &&
+	       a.ys[0] == b.ys[0] && a.ys[1] == b.ys[1];
+}
+
+bool stream_is_capturing(hipStream_t stream)
+{
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	return cs != hipStreamCaptureStatusNone;
+}
 }
 
 extern "C" void ROLL_NAME(fixca_roll_release_tables)(void)
 {
-
 	for (TableEntry &e : g_tc) {
 		if (e.mem) (void)hipFree(e.mem);
 		if (e.ready) (void)hipEventDestroy(e.ready);
+		if (e.last_use) (void)hipEventDestroy(e.last_use);
 		e = TableEntry();
 	}
 }
 
-static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream, RollTables *out)
+/* after a launch that reads entry t's tables on `stream` */
+static hipError_t tables_mark_used(TableEntry *t, hipStream_t stream)
 {
-	FixcaGeom key = *g;
-	key.y1 = key.y2 = 0;
-	key.preview = 0;
+	if (stream_is_capturing(stream)) {
+		t->pinned = true;
+		return hipSuccess;
+	}
+	hipError_t e;
+	if (!t->last_use) {
+		e = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming);
+		if (e != hipSuccess) return e;
+	}
+	if (t->used && t->last_stream != stream) {
+		/* an earlier reader on another stream may still be running: the new record must not forget it */
+		if (hipEventQuery(t->last_use) != hipSuccess) {
+			(void)hipGetLastError();
+			e = hipStreamWaitEvent(stream, t->last_use, 0);
+			if (e != hipSuccess) return e;
+		}
+	}
+	e = hipEventRecord(t->last_use, stream);
+	if (e != hipSuccess) return e;
+	t->used = true;
+	t->last_stream = stream;
+	return hipSuccess;
+}
+
+static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream, RollTables *out, TableEntry **entry)
+{
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess) return e;
 	for (TableEntry &t : g_tc) {
-		if (t.valid && t.device == dev && t.oc == pl->oc && memcmp(&t.g, &key, sizeof key) == 0) {
+		if (t.valid && t.device == dev && t.oc == pl->oc && same_tables(t.g, *g)) {
 			/* always ordered after the table kernel: a stream handle can be destroyed and handed out
 			 * again, so "the stream that built them" proves nothing, and the wait costs next to nothing */
 			e = hipStreamWaitEvent(stream, t.ready, 0);
 			if (e != hipSuccess) return e;
-			t.used = ++g_tick;
+			t.tick = ++g_tick;
 			*out = t.tb;
+			*entry = &t;
 			return hipSuccess;
 		}
 	}
-	TableEntry *slot = nullptr;                      /* a free entry, else the least recently used */
+	TableEntry *slot = nullptr;                      /* a free entry, else the least recently used one that no graph holds */
 	for (TableEntry &t : g_tc)
 		if (!t.valid) { slot = &t; break; }
 	if (!slot) {
-		slot = &g_tc[0];
 		for (TableEntry &t : g_tc)
-			if (t.used < slot->used) slot = &t;
+			if (!t.pinned && (!slot || t.tick < slot->tick)) slot = &t;
+	}
+	if (!slot) {
+		fixca_fail(-4, "all %d table entries of this thread are held by captured launches: fixca_release_cache() after the graphs are destroyed", TABLE_ENTRIES);
+		return hipErrorOutOfMemory;
 	}
 	TableEntry &t = *slot;
 	if (t.valid) {
-		/* eviction: kernels on any stream may still be reading this entry's tables.  (Not legal
-		 * inside a stream capture: a capture must not bring a 9th geometry; fixca_hip.h says so.) */
-		e = hipDeviceSynchronize();
+		/* eviction: the last kernel that read this entry's tables must have finished (and with it, on its stream, every
+		 * earlier one; readers on other streams were chained into last_use by tables_mark_used) */
+		if (t.used) {
+			e = hipEventSynchronize(t.last_use);
+			if (e != hipSuccess) return e;
+		}
+		e = hipEventSynchronize(t.ready);
 		if (e != hipSuccess) return e;
 		t.valid = false;
+		t.used = false;
 	}
 	const size_t n_strips = (size_t)pl->nstrips;
 	const size_t off_colw = (n_strips * sizeof(RollStrip) + 255) & ~(size_t)255;
@@ -940,13 +997,14 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	e = hipEventRecord(t.ready, stream);
 	if (e != hipSuccess) return e;
 	t.valid = true;
+	t.pinned = false;
 	t.device = dev;
-	t.g = key;
+	t.g = *g;
 	t.oc = pl->oc;
 	t.tb = tb;
-	t.built_on = stream;
-	t.used = ++g_tick;
+	t.tick = ++g_tick;
 	*out = tb;
+	*entry = &t;
 	return hipSuccess;
 }
 
@@ -962,7 +1020,8 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 		imgs.dst[i] = static_cast<uint8_t *>(d_dst[i < n_images ? i : 0]);
 	}
 	RollTables tb;
-	hipError_t e = ensure_tables(g, pl, stream, &tb);
+	TableEntry *entry = nullptr;
+	hipError_t e = ensure_tables(g, pl, stream, &tb, &entry);
 	if (e != hipSuccess) return e;
 	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	lds += (size_t)fixca_debug_env("FIXCA_EXP_LDS_PAD", 0, 0, 128 * 1024);      /* timing experiment: fewer waves per CU */
@@ -988,7 +1047,9 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
 		else                     hipLaunchKernelGGL((k_roll<4, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
 	}
-	return hipGetLastError();
+	e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	return tables_mark_used(entry, stream);
 }
 
 extern "C" hipError_t

@@ -13,6 +13,8 @@
 struct FixcaGeom;
 /* waves of the geometry's k_wcol instantiation the device holds at once, 0 if there is no device to ask (fixca_wide.hip) */
 extern "C" int fixca_wide_slots(const struct FixcaGeom *g, int fast);
+/* the current HIP device (-1: none); k_wcol's tile height depends on it, so the planner's caches are keyed by it */
+extern "C" int fixca_wide_device(void);
 
 struct WidePlan {
 	int oc, th, nstrips, nwaves, nblocks;

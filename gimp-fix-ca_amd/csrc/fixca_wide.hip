@@ -185,15 +185,18 @@ __device__ __forceinline__ int tap_index_rt(int c0, int t, int n) { return max(0
  * x = sum_t wy_t(fy) * sum_i wx_i(fx) * s_ti with the Catmull-Rom weights below, 8 fused multiply-adds on the integer
  * samples.  The two differ only by rounding errors: every one of the reference's 19 + 19 operations and 16 divisions
  * rounds a value of magnitude <= 12 (in units of p) by <= 2^-53 relative, the second filter multiplies the first one's
- * errors by at most sum |w| <= 1.5, so |x_ref - x| <= (230 + 1.5 * 230 + 16) * 12 * 1.2e-16 * 65535 < 6e-9 samples, and
- * the weight form's own error is below 1e-9 (measured over 6e7 random, extreme-step and nearly flat windows, numpy
- * against the operation-for-operation form: 9.8e-11).  The rounded sample can differ only when a rounding boundary
- * k + 0.5 lies between the two values (clipping to [0, 65535] moves both to the same integer): so x is rounded as the
- * reference rounds, and the rare sample whose fraction is within WIDE_FAST_EPS = 1e-6 of 0.5 (160 x the bound) is
+ * errors by at most sum |w| <= 1.5, so |x_ref - x| <= (230 + 1.5 * 230 + 16) * 12 * 1.2e-16 * 65535 = 5.6e-8 samples
+ * (a worst-case bound: every operation at full magnitude with errors of one sign), and the weight form's own error is
+ * below 1e-9 (measured over 6e7 random, extreme-step and nearly flat windows, numpy against the operation-for-operation
+ * form: 9.8e-11; tests/c/weightbound.c measures a largest difference of 8.4e-11 between the two forms and asserts
+ * < 1e-8).  The rounded sample can differ only when a rounding boundary k + 0.5 lies between the two values (clipping
+ * to [0, 65535] moves both to the same integer): so x is rounded as the reference rounds, and the rare sample whose
+ * fraction is within WIDE_FAST_EPS = 1e-6 of 0.5 (18 x the analytic bound, 10^4 x the measured difference) is
  * recomputed operation for operation from the source image (exact_cubic_sample, the one-thread-per-pixel kernel's
  * code).  The planner (plan_wide) keeps the operation-for-operation variant for geometries whose fractions sit on a
  * coarse dyadic grid (pure shifts by halves or quarters), where such samples are common. */
 #define WIDE_FAST_EPS 1e-6
+static_assert(WIDE_FAST_EPS >= 10 * 5.6e-8, "the recheck band must stay at least 10 x the analytic bound on |x_ref - x|");
 __device__ __forceinline__ void cr_weights(double t, double (&w)[4])
 {
 	const double t2 = t * t, t3 = t2 * t;
@@ -599,9 +602,16 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				/* my four results as samples, pixel-major, into LDS (the converted-sample buffer is free until the next row's
 				 * convert(); a wave's LDS operations complete in order); then each lane picks up the red and blue of the units
 				 * it holds: unit = pixel for 16-byte pixels; for 32-byte pixels even units are (R, G), odd ones (B, A) */
+				/* hbuf is declared double and convert() stores doubles into it; here the same bytes are written and read as
+				 * samples.  The compiler orders memory accesses by type, so without the fences it may move the next row's
+				 * double stores above this row's sample reads (or these sample stores above the filters' double reads):
+				 * the empty asm statements pin the order, as in the STAGED path; the hardware completes a wave's LDS
+				 * operations in order. */
+				asm volatile("" ::: "memory");
 				S *res = reinterpret_cast<S *>(&hbuf[0][0]);
 				res[4 * lane + 0] = outv[0][0]; res[4 * lane + 1] = outv[1][0];
 				res[4 * lane + 2] = outv[0][1]; res[4 * lane + 3] = outv[1][1];
+				asm volatile("" ::: "memory");
 				const rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(dst) + (size_t)(Y0 + min(r, nrows - 1)) * pitchB, 0,
 				                                                      live ? pitchB : 0u, 0x00020000);
 #pragma unroll
@@ -612,6 +622,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 					else set_sample<S>(px, 2 * i, res[u]);
 					store_dwords<4>(rrow, ustore[i], 0, px + 4 * i);
 				}
+				asm volatile("" ::: "memory");                  /* the read-back is done before the next row's convert() writes */
 			} else if constexpr (STAGED) {
 				const rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(dst) + (size_t)(Y0 + min(r, nrows - 1)) * pitchB, 0,
 				                                                      live ? pitchB : 0u, 0x00020000);
@@ -748,16 +759,22 @@ extern "C" int
 fixca_wide_slots(const FixcaGeom *g, int fast)
 {
 	static std::mutex mu;
-	static int cached_all[2][4][12];
-	int (&cached)[4][12] = cached_all[fast ? 1 : 0];                              /* 0 = not asked yet, -1 = cannot be asked */
+	constexpr int MAXDEV = 16;                          /* answers are per device: CU count and occupancy may differ */
+	static int cached_all[MAXDEV][2][4][12];
 	const int ti = wcol_type_index(g->bpc);
 	if (ti < 0 || g->interp < 0 || g->interp > 2) return 0;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	if (dev < 0 || dev >= MAXDEV) return 0;
+	int (&cached)[4][12] = cached_all[dev][fast ? 1 : 0];                         /* 0 = not asked yet, -1 = cannot be asked */
 	const int sel = wcol_selector(g);
 	std::lock_guard<std::mutex> lock(mu);
 	if (cached[ti][sel] == 0) {
-		int per_cu = 0, dev = 0, cus = 0;
-		if (hipGetDevice(&dev) == hipSuccess &&
-		    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+		int per_cu = 0, cus = 0;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
 		    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wcol_kernel_for(g, fast != 0), 64, 0) == hipSuccess && per_cu > 0 && cus > 0)
 			cached[ti][sel] = per_cu * cus;
 		else {
@@ -766,6 +783,19 @@ fixca_wide_slots(const FixcaGeom *g, int fast)
 		}
 	}
 	return cached[ti][sel] > 0 ? cached[ti][sel] : 0;
+}
+
+/* the current device, -1 when there is none: part of the planner's cache key for the sample types whose tile height
+ * comes from fixca_wide_slots */
+extern "C" int
+fixca_wide_device(void)
+{
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return -1;
+	}
+	return dev;
 }
 
 extern "C" hipError_t

@@ -59,9 +59,14 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 	if (!dest) dest = malloc(total);                        /* no GPU: the call below reports it */
 	if (!dest) return -1;
 
-	/* The reference passes the selection rectangle (fix-ca.c:373-374) although only
-	 * full-width regions are indexed correctly.  A full-width selection
-	 * is processed as the reference does; a narrower one is refused by the shim. */
+	/* FIX, NOT REPLICATE.  The reference is broken for every selection that is not the whole
+	 * drawable: it fetches the selection rectangle tightly packed at offset 0 of srcImg (fix-ca.c:369-370,
+	 * GEGL_AUTO_ROWSTRIDE) and then indexes that buffer with IMAGE rows and the image width (fix-ca.c:373-374,
+	 * :855), so a full-width selection with y != 0 reads rows that were never fetched, and x != 0 is wrong three
+	 * more ways.  This mirror does the sane thing instead: the drawable is held whole, rows
+	 * [sel_y, sel_y + sel_h) of it are corrected in place of the image (what a user selecting a band of rows
+	 * expects), and a selection narrower than the image is refused by the shim (FIXCA_E_UNSUPPORTED).  For the
+	 * whole drawable - the only case in which the reference's output is defined - the two agree. */
 	fix_ca_region(d->pixels, dest, d->width, d->height, d->bpp, d->bpc, params,
 	              d->sel_x, d->sel_x + d->sel_w, d->sel_y, d->sel_y + d->sel_h, 1);
 	if (fixca_host_status != FIXCA_OK) {

@@ -76,18 +76,37 @@ FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
 /*
  * A batch of independent images of one geometry and one parameter block (the
  * "512 images" configuration): image i is d_src[i] -> d_dst[i], all rows.  The
- * pointer arrays are host arrays of device pointers.  One launch per image, back
- * to back on `stream`.
+ * pointer arrays are host arrays of device pointers (read during the call, not kept).
+ * Asynchronous on `stream`.  Launches: 8-bit samples through the row-rolling kernel take
+ * up to 128 images per kernel launch, interpolation NONE on the wider sample types up to
+ * 32, every other kernel one image per launch, all back to back on `stream`.
+ *
+ * Stream capture: once a geometry's tables exist (one earlier call with the same size,
+ * parameters and sample format on any stream), the call makes no allocation and no
+ * synchronisation and may be captured into a graph.  The tables a captured launch reads
+ * are then kept until fixca_release_cache(); a thread holds at most 8 such geometries
+ * (the 9th call under capture fails with FIXCA_E_HIP).  A capture must not be the FIRST
+ * call of a geometry: that call allocates the tables.
  */
 FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, int n_images,
                                  int orig_width, int orig_height, int bytes, int bpc,
                                  const FIXCA_PARAMS_T *params, unsigned flags, void *stream);
 
 /*
- * Which kernel the planner picks for a call, without launching anything (usable
- * with no GPU).  Writes a short description ("fast-cubic oc=248 th=32 ...") into
- * buf and returns the kernel id: 1 = exact, 2 = fast-none, 3 = fast-interp;
- * negative FIXCA_E_* if the call itself would be refused.
+ * Which kernel the planner picks for a call, without launching anything.  Writes a short
+ * description ("roll cubic bpp=4 oc=240 th=57 ring=16 ...") into buf and returns the
+ * kernel id, or a negative FIXCA_E_* if the call itself would be refused:
+ *   1 exact-fp64      one thread per pixel, the reference's arithmetic operation for operation
+ *                     (every sample type; FIXCA_KERNEL_EXACT, and the fallback of the wide types)
+ *   2 fast-none       8-bit register-window gather (widths the ring kernels refuse)
+ *   3 fast-interp     8-bit register-window LINEAR / CUBIC (likewise)
+ *   4 scan            8-bit LDS-ring row scan (scales far from 1)
+ *   6 roll            8-bit LDS-ring row-rolling kernel, RGBA8 and RGB8: the main kernel
+ *   7 wide-roll-fp64  u16 / u32 / float / double, LINEAR and CUBIC, fp64 rolling window
+ *   8 move-none       u16 / u32 / float / double, NONE: LDS-ring byte mover
+ * (5 is retired.)  Usable with no GPU: nothing is launched.  For LINEAR / CUBIC on the wide
+ * sample types the planner asks the HIP runtime for the current device's occupancy (this
+ * may initialise the runtime); without a device it plans for a 256-CU part.
  */
 FIXCA_API int fixca_plan_describe(int orig_width, int orig_height, int bytes, int bpc,
                                   const FIXCA_PARAMS_T *params, int x1, int x2, int y1, int y2,

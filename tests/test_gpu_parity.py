@@ -623,6 +623,30 @@ def test_table_cache_across_geometries_and_streams(torch_cuda):
         assert mx <= TOL_LSB
 
 
+def test_table_cache_evicts_without_stalling_other_work(torch_cuda):
+    """An interactive preview that drags a slider brings a new parameter block per call: after 8 geometries every call
+    evicts the least recently used tables.  Eviction waits for that entry's last reader only; results stay right over
+    20 parameter blocks on two streams, and the first geometry (evicted long ago) is rebuilt correctly."""
+    torch = torch_cuda
+    w, h = 512, 64
+    img = synth.noise_image(77, w, h, 4)
+    src = torch.from_numpy(img).cuda()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for k in list(range(20)) + [0]:
+        p = fixca.make_params(blue=0.5 + 0.07 * k, red=-0.4, lens_x=300, lens_y=20, interpolation=2, x_blue=0.25 * (k % 3))
+        assert fixca.plan(w, h, 4, 1, p)[0] == 6
+        dst = torch.empty_like(src)
+        with torch.cuda.stream(streams[k % 2]):
+            fixca.fix_ca_region(src, dst, w, h, 4, 1, p, 0, w, 0, h, True)
+        outs.append((dst, p))
+    torch.cuda.synchronize()
+    for dst, p in outs:
+        mx, _ = diff_stats(dst.cpu().numpy(), oracle_run(img, p))
+        assert mx <= TOL_LSB
+    fixca.lib.fixca_release_cache()
+
+
 def test_batch_entry_replays_from_a_hip_graph(torch_cuda):
     """the batch entry makes no allocation or synchronisation once its tables exist, so a caller
     can capture it into a graph and replay it on new pixel data"""
@@ -648,6 +672,21 @@ def test_batch_entry_replays_from_a_hip_graph(torch_cuda):
     for a, d in zip(new, dsts):
         mx, _ = diff_stats(d.cpu().numpy(), oracle_run(a, p))
         assert mx <= TOL_LSB
+    # the captured launch reads this geometry's tables whenever the graph replays: ten other geometries pass through
+    # the 8-entry cache and must not evict them
+    small = torch.from_numpy(synth.noise_image(5, 512, 40, 4)).cuda()
+    for k in range(10):
+        q = fixca.make_params(blue=0.3 + 0.1 * k, red=-0.2, lens_x=100, lens_y=10, interpolation=1)
+        fixca.fix_ca_region(small, torch.empty_like(small), 512, 40, 4, 1, q, 0, 512, 0, 40, True)
+    for d in dsts:
+        d.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, d in zip(new, dsts):
+        mx, _ = diff_stats(d.cpu().numpy(), oracle_run(a, p))
+        assert mx <= TOL_LSB
+    del graph
+    fixca.lib.fixca_release_cache()
 
 
 def test_batch_full_size_images_0_31_32_last(torch_cuda):

@@ -127,12 +127,21 @@ def test_no_store_data_hazard_in_kernels(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import store_hazard_scan
-    for src in ("fixca_wide.hip", "fixca_roll.hip"):
+    # every translation unit of the library (the Makefile's HIPSRCS): the RGB8 compilation of the rolling kernel stores
+    # 12 bytes per lane, the NONE mover 16, and a compiler change could bring the hazard back in any of them
+    mk = open(os.path.join(root, "gimp-fix-ca_amd", "csrc", "Makefile")).read()
+    srcs = re.search(r"^HIPSRCS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert {"fixca_wide.hip", "fixca_roll.hip", "fixca_roll_rgb.hip", "fixca_move.hip"} <= set(srcs)
+    flags = re.search(r"^CXXFLAGS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    nstores = 0
+    for src in srcs:
         out = tmp_path / (src + ".s")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+        subprocess.run([hipcc, "--offload-arch=gfx950"] + flags + ["-S", "--cuda-device-only",
                         os.path.join(root, "gimp-fix-ca_amd", "csrc", src), "-o", str(out)], check=True, capture_output=True)
+        nstores += sum(1 for l in open(out) if re.match(r"\s+(buffer|global)_store_dwordx[34]\s", l))
         direct = [h for h in store_hazard_scan.scan(str(out)) if "(+1)" in h]
         assert not direct, direct[:3]
+    assert nstores > 50                                  # the scan saw the stores it is about
 
 
 def test_bench_launcher_relays_the_ranks_exit_code(repo_root):

@@ -19,17 +19,25 @@ CSRC = os.path.join(ROOT, "gimp-fix-ca_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def roll_asm(tmp_path_factory):
+def _asm(tmp_path_factory, source):
     if not os.path.exists(HIPCC) and not shutil.which("hipcc"):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "roll.s"
+    out = tmp_path_factory.mktemp("isa") / (source + ".s")
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
                            "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(CSRC, "fixca_roll.hip")], stderr=subprocess.DEVNULL)
-    lines = [l for l in out.read_text().split("\n")
-             if l.startswith("\t") and not l.strip().startswith((";", "."))]
-    return lines
+                           os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
+    return [l for l in out.read_text().split("\n")
+            if l.startswith("\t") and not l.strip().startswith((";", "."))]
+
+
+@pytest.fixture(scope="module")
+def roll_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "fixca_roll.hip")
+
+
+@pytest.fixture(scope="module")
+def roll_rgb_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "fixca_roll_rgb.hip")
 
 
 def _dst_regs(line):
@@ -43,17 +51,38 @@ def _dst_regs(line):
     return {int(m.group(1))} if m else set()
 
 
-def test_dpp_sources_are_not_fresh_valu_results(roll_asm):
+def _check_dpp(asm, at_least):
     ndpp = 0
-    for i, l in enumerate(roll_asm):
+    for i, l in enumerate(asm):
         if "_dpp" not in l:
             continue
         ndpp += 1
         src = int(re.match(r"v(\d+)$", l.strip().replace(",", " ").split()[2]).group(1))
         for back in (1, 2):
-            p = roll_asm[i - back].strip()
+            p = asm[i - back].strip()
             assert not (p.startswith("v_") and src in _dst_regs(p)), "DPP hazard: %s -> %s" % (p, l.strip())
-    assert ndpp >= 16            # the conversions are there at all
+    assert ndpp >= at_least      # the conversions are there at all
+
+
+def test_dpp_sources_are_not_fresh_valu_results(roll_asm):
+    _check_dpp(roll_asm, 16)
+
+
+def test_rgb8_tap_windows_are_picked_by_conversion_not_by_shifts(roll_rgb_asm):
+    """RGB8 (fixca_roll_rgb.hip): the byte alignment of a lane's 12-byte tap window is a constant of each of four
+    instantiations, so the bytes are picked by v_cvt_f32_ubyteN (own pixels) and v_cvt_f32_ubyteN_dpp (the next lane's):
+    no v_alignbyte and no v_mov_dpp in the kernel, and all four byte selectors occur in DPP form.  The hand-written DPP
+    conversions read LDS-load results only (the hazard the RGBA test checks)."""
+    _check_dpp(roll_rgb_asm, 64)
+    text = "\n".join(roll_rgb_asm)
+    assert "v_alignbyte_b32" not in text and "v_mov_b32_dpp" not in text
+    for k in range(4):
+        assert "v_cvt_f32_ubyte%d_dpp" % k in text
+    stores = [l.strip() for l in roll_rgb_asm if l.strip().startswith("buffer_store_dwordx3")]
+    assert stores
+    for st in stores:                                   # same store rule as RGBA: the scalar offset is the literal 0
+        ops = [o.strip() for o in st.split(None, 1)[1].split(",")]
+        assert ops[3].split()[0] == "0", st
 
 
 def test_row_stores_keep_soffset_constant(roll_asm):

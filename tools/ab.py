@@ -159,7 +159,10 @@ for r in range(a.rounds):
                 if not torch.equal(dst[N - 1], ref):
                     print("!! %s: output differs from %s in %d bytes" % (name, name0, int((dst[N - 1] != ref).sum())))
 algo = 2.0 * PB * W * H
-print("%dx%d bpp=%d bpc=%d interp=%d, %d images, %s" % (W, H, a.bpp, a.bpc, a.interp, N, "one image per launch" if a.single else "batch entry"))
+# the box's own yardstick on the same buffers: the library's 16-byte-per-lane nt copy kernel
+copy_ms = fixca.time_copy([src[i] for i in range(N)], [dst[i] for i in range(N)], max(64, 4 * N), W * H * PB)
+print("%dx%d bpp=%d bpc=%d interp=%d, %d images, %s; nt copy of the same buffers: %.1f %%" % (
+    W, H, a.bpp, a.bpc, a.interp, N, "one image per launch" if a.single else "batch entry", algo / (copy_ms * 1e3) / 1e3 / 80))
 for name, path, env, per in VARIANTS:
     v = res[name]
     if not v:
