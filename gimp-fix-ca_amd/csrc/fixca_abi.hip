@@ -42,6 +42,28 @@ int fixca_fail(int code, const char *fmt, ...)
 }
 
 extern "C" const char *fixca_last_error(void) { return g_err; }
+
+/* FIXCA_PHASES=1: time stamps of a call's phases on stderr ("fixca-phase <name> <ms>"), in milliseconds of
+ * CLOCK_MONOTONIC since FIXCA_T0_NS (the spawning process puts its own clock reading there: the clock is system
+ * wide) or since the first stamp.  bench.py's cold_call leg reads them; off by default, one getenv per process. */
+#include <time.h>
+extern "C" void fixca_phase(const char *name)
+{
+	static int on = -1;
+	static long long t0 = 0;
+	if (on < 0) {
+		const char *e = getenv("FIXCA_PHASES");
+		on = (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
+		const char *z = getenv("FIXCA_T0_NS");
+		if (z && *z) t0 = atoll(z);
+	}
+	if (!on) return;
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	const long long now = (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+	if (!t0) t0 = now;
+	fprintf(stderr, "fixca-phase %s %.3f\n", name, (double)(now - t0) / 1e6);
+}
 extern "C" int fixca_abi_version(void) { return 1; }
 
 #define HIP_TRY(call)                                                                       \
@@ -304,8 +326,10 @@ static int region_host_queue(const unsigned char *src, unsigned char *dst, int W
 {
 	int rc;
 	const size_t pitch = (size_t)W * bytes, total = pitch * H;
+	fixca_phase("region_host:entered");
 	rc = host_cache_reserve(total);
 	if (rc) return rc;
+	fixca_phase("region_host:device_images_allocated");
 	const char *ex = getenv("FIXCA_EXACT");
 	const unsigned flags = (ex && *ex && strcmp(ex, "0") != 0) ? FIXCA_KERNEL_EXACT : FIXCA_KERNEL_AUTO;
 	char *const d_src = static_cast<char *>(g_cache.buf[0]);
@@ -320,10 +344,13 @@ static int region_host_queue(const unsigned char *src, unsigned char *dst, int W
 
 	if (rows < 256 || fixca_debug_flag("FIXCA_NO_PIPELINE") || !is_pinned(src) || !is_pinned(dst)) {
 		HIP_TRY(hipMemcpy(d_src + (size_t)lo * pitch, src + (size_t)lo * pitch, (size_t)(hi - lo) * pitch, hipMemcpyHostToDevice));
+		fixca_phase("region_host:uploaded");
 		rc = fixca_region_device(d_src, d_dst, W, H, bytes, bpc, params, x1, x2, y1, y2, show_progress, flags, NULL);
 		if (rc) return rc;
+		fixca_phase("region_host:kernel_launched");
 		HIP_TRY(hipMemcpy(dst + (size_t)y1 * pitch, d_dst + (size_t)y1 * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost));
 		HIP_TRY(hipDeviceSynchronize());
+		fixca_phase("region_host:downloaded");
 		return FIXCA_OK;
 	}
 
@@ -332,6 +359,7 @@ static int region_host_queue(const unsigned char *src, unsigned char *dst, int W
 	 * the kernel (PCIe is full duplex). */
 	rc = pipe_init();
 	if (rc) return rc;
+	fixca_phase("region_host:streams_ready");
 	int bh = (rows + PIPE_BANDS - 1) / PIPE_BANDS;
 	bh = (bh + 3) & ~3;
 	int up_to = lo, band = 0;
@@ -352,9 +380,11 @@ static int region_host_queue(const unsigned char *src, unsigned char *dst, int W
 		HIP_TRY(hipMemcpyAsync(dst + (size_t)yb * pitch, d_dst + (size_t)yb * pitch, (size_t)(ye - yb) * pitch,
 		                       hipMemcpyDeviceToHost, g_pipe.down));
 	}
+	fixca_phase("region_host:bands_queued");
 	HIP_TRY(hipStreamSynchronize(g_pipe.down));
 	HIP_TRY(hipStreamSynchronize(g_pipe.run));
 	HIP_TRY(hipStreamSynchronize(g_pipe.up));
+	fixca_phase("region_host:downloaded");
 	return FIXCA_OK;
 }
 

@@ -101,6 +101,7 @@ def _load():
         "fixca_noise_device": ([vp, ctypes.c_size_t, ctypes.c_ulonglong, vp], ci),
         "fixca_debug_sched": ([ci, ci, ci, P, ci, ctypes.POINTER(ci)], ci),
         "fixca_debug_host_cache": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)], None),
+        "fixca_phase": ([ctypes.c_char_p], None),
         "fixca_last_error": ([], ctypes.c_char_p),
         "fixca_abi_version": ([], ci),
     }

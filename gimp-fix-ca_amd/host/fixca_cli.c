@@ -8,7 +8,9 @@
  * Arguments are marshalled into PDB-shaped values and go through
  * fixca_unmarshal_noninteractive(), so omitted arguments take run()'s defaults.
  * Pass --lens-as-float to give lens_x/lens_y directly instead of through the
- * reference's d_int32 read.
+ * reference's d_int32 read; --pinned to page-lock the two images (pays off only for a
+ * host that lives for many calls: a PDB call is one process, one image).
+ * FIXCA_PHASES=1 prints the call's phases with time stamps on stderr (fixca_phase).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,9 +74,9 @@ static unsigned char *read_image(const char *path, int *w, int *h, int *bpp)
 		*bpp = 4;
 	} else goto done;
 	if (*w <= 0 || *h <= 0) goto done;
-	px = fixca_host_alloc((size_t)*w * *h * *bpp);      /* page-locked: see fixca_host.c */
+	px = fixca_host_use_pinned ? fixca_host_alloc((size_t)*w * *h * *bpp) : NULL;      /* page-locked: see fixca_host.c */
 	pixels_pinned = px != NULL;
-	if (!px) px = malloc((size_t)*w * *h * *bpp);       /* no GPU: fix_ca() reports it */
+	if (!px) px = malloc((size_t)*w * *h * *bpp);       /* g_new at fix-ca.c:366 */
 	if (px && fread(px, (size_t)*w * *bpp, *h, f) != (size_t)*h) { release_pixels(px); px = NULL; }
 done:
 	fclose(f);
@@ -100,8 +102,11 @@ int main(int argc, char **argv)
 	int lens_float = 0, n = 0, i;
 	const char *pos[16];
 
+	fixca_phase("cli:main_entered");           /* after the dynamic loader: libfixca_hip.so, the HIP runtime and their constructors */
+
 	for (i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--lens-as-float")) lens_float = 1;
+		else if (!strcmp(argv[i], "--pinned")) fixca_host_use_pinned = 1;
 		else if (n < 16) pos[n++] = argv[i];
 	}
 	if (n < 4 || n > 11) {
@@ -122,10 +127,14 @@ int main(int argc, char **argv)
 	memset(&d, 0, sizeof d);
 	d.pixels = read_image(pos[0], &d.width, &d.height, &d.bpp);
 	if (!d.pixels) { fprintf(stderr, "cannot read %s (binary P6 or P7/RGB_ALPHA, maxval 255)\n", pos[0]); return 1; }
+	fixca_phase("cli:image_read");
 	d.bpc = fixca_color_size(d.bpp == 4 ? "R'G'B'A u8" : "R'G'B' u8", d.bpp);
 	d.sel_x = 0; d.sel_y = 0; d.sel_w = d.width; d.sel_h = d.height;
 	if (fix_ca(&d, &p)) return 1;
+	fixca_phase("cli:fix_ca_returned");
 	if (write_image(pos[1], d.pixels, d.width, d.height, d.bpp)) { fprintf(stderr, "cannot write %s\n", pos[1]); return 1; }
+	fixca_phase("cli:image_written");
 	release_pixels(d.pixels);
+	fixca_phase("cli:exiting");
 	return 0;
 }

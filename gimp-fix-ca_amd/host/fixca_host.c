@@ -11,6 +11,10 @@
 #include "fixca_host.h"
 
 int fixca_host_status = FIXCA_OK;
+/* 1: fix_ca() page-locks its result image (fixca_host_alloc).  Worth it for a long-lived host that calls again and
+ * again (the copies then overlap with the kernel in row bands); a plug-in process lives for ONE call, and page-locking
+ * 96 MB costs more than the pipelining saves (bench.py's cold_call_ms.phases), so the default is off. */
+int fixca_host_use_pinned = 0;
 
 void fix_ca_region(unsigned char *srcPTR, unsigned char *dstPTR,
                    int orig_width, int orig_height, int bytes, int bpc,
@@ -54,10 +58,11 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 	total = (size_t)d->width * d->height * d->bpp;
 	/* page-locked like the reference's g_new'ed destImg would be with fixca_host_alloc:
 	 * with a page-locked source too, fixca_region_host pipelines upload, kernel and download */
-	dest = fixca_host_alloc(total);
+	dest = fixca_host_use_pinned ? fixca_host_alloc(total) : NULL;
 	pinned = dest != NULL;
-	if (!dest) dest = malloc(total);                        /* no GPU: the call below reports it */
+	if (!dest) dest = malloc(total);                        /* g_new at fix-ca.c:367 */
 	if (!dest) return -1;
+	fixca_phase("fix_ca:result_image_allocated");
 
 	/* FIX, NOT REPLICATE.  The reference is broken for every selection that is not the whole
 	 * drawable: it fetches the selection rectangle tightly packed at offset 0 of srcImg (fix-ca.c:369-370,
@@ -73,6 +78,7 @@ int fix_ca(FixcaDrawable *d, FixCaParams *params)
 		if (pinned) fixca_host_free(dest); else free(dest);
 		return -1;
 	}
+	fixca_phase("fix_ca:region_done");
 	/* gegl_buffer_set of the rectangle + merge_shadow (fix-ca.c:376-385) */
 	memcpy(d->pixels + (size_t)d->sel_y * d->width * d->bpp,
 	       dest + (size_t)d->sel_y * d->width * d->bpp,

@@ -56,6 +56,10 @@ int fix_ca(FixcaDrawable *drawable, FixCaParams *params);
 int fixca_preview_pixels(const FixcaDrawable *drawable, FixCaParams *params,
                          int x, int y, int width, int height, unsigned char *prevImg);
 
+/* 1: fix_ca() page-locks its result image with fixca_host_alloc (long-lived hosts); 0 (default): malloc, as the
+ * reference's g_new (fix-ca.c:366-367): a plug-in process lives for one call. */
+extern int fixca_host_use_pinned;
+
 /* color_size() (fix-ca.c:681-711) from a babl format name and bytes per pixel. */
 int fixca_color_size(const char *babl_format_name, int bytes_per_pixel);
 

@@ -182,6 +182,13 @@ FIXCA_API int fixca_time_launches(const void *const *d_src, void *const *d_dst, 
 FIXCA_API int fixca_time_copy(const void *const *d_src, void *const *d_dst, int n_pairs,
                               int launches, size_t nbytes, void *stream, double *ms_per_launch);
 
+/*
+ * With FIXCA_PHASES=1 in the environment: writes "fixca-phase <name> <ms>" to stderr, ms of CLOCK_MONOTONIC since
+ * FIXCA_T0_NS (a clock reading of the spawning process) or since the first stamp; a no-op otherwise.  The library
+ * stamps the phases of fixca_region_host; a host may add its own (fixca_cli does).
+ */
+FIXCA_API void fixca_phase(const char *name);
+
 FIXCA_API const char *fixca_last_error(void);          /* thread-local, never NULL     */
 FIXCA_API int         fixca_abi_version(void);         /* 1                            */
 
