@@ -466,7 +466,7 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
  * Scales other than 1 spread the fractions over the columns and rows and such samples are a few per image. */
 static bool wide_fast_ok(const FixcaGeom *g)
 {
-	if (g->bpc != 2 || g->interp == 0 || fixca_debug_flag("FIXCA_WCOL_REF")) return false;       /* 16-bit samples, LINEAR and CUBIC */
+	if (g->bpc != 2 || g->interp != 2 || fixca_debug_flag("FIXCA_WCOL_REF")) return false;
 	if (fixca_debug_flag("FIXCA_WCOL_WEIGHTS")) return true;          /* tests: the recomputation path under load */
 	const int rows = g->y2 - g->y1;
 	for (int c = 0; c < 2; ++c) {

@@ -224,24 +224,6 @@ __device__ __forceinline__ S exact_cubic_sample(const S *__restrict__ src, const
 	return C::put(clip01(cr_exact(h[0], h[1], h[2], h[3], fy)));
 }
 
-/* the same for LINEAR (fix-ca.c:1160-1185, bilinear :882-894) */
-template <typename S, int NCH>
-__device__ __forceinline__ S exact_linear_sample(const S *__restrict__ src, const FixcaGeom &g, int x, int y, int c)
-{
-	typedef Codec<S> C;
-	const size_t pitch = (size_t)g.W * NCH;
-	const double yd = map_dbl(y, g.yc, g.H, g.s[c], g.ys[c]), xd = map_dbl(x, g.xc, g.W, g.s[c], g.xs[c]);
-	const int r0 = (int)floor(yd), c0 = (int)floor(xd);
-	const double fy = __dsub_rn(yd, (double)r0), fx = __dsub_rn(xd, (double)c0);
-	const int r1 = (r0 == g.H - 1) ? r0 : r0 + 1, c1 = (c0 == g.W - 1) ? c0 : c0 + 1;
-	const S *row0 = src + (size_t)r0 * pitch + 2 * c, *row1 = src + (size_t)r1 * pitch + 2 * c;
-	const double p00 = C::get(row0[(size_t)c0 * NCH]), p10 = C::get(row0[(size_t)c1 * NCH]);
-	const double p01 = C::get(row1[(size_t)c0 * NCH]), p11 = C::get(row1[(size_t)c1 * NCH]);
-	const double a = __dadd_rn(p00, __dmul_rn(fx, __dsub_rn(p10, p00)));
-	const double b = __dadd_rn(p01, __dmul_rn(fx, __dsub_rn(p11, p01)));
-	return C::put(clip01(__dadd_rn(__dmul_rn(__dsub_rn(1.0, fy), a), __dmul_rn(fy, b))));
-}
-
 /* tap t of the window that starts at integer coordinate c0, clamped as the reference clamps it:
  * cubic  max(c0-1,0), c0, min(c0+1,n-1), min(min(c0+1,n-1)+1,n-1)  (fix-ca.c:1218-1256, 1270-1298)
  * linear c0, (c0 == n-1) ? c0 : c0+1                               (fix-ca.c:1149-1158, 1170-1177)
@@ -275,7 +257,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 {
 	typedef Codec<S> C;
 	constexpr int T = TAPS, BACK = (T == 4) ? 1 : 0;
-	static_assert(!FAST || (sizeof(S) == 2 && TAPS >= 2), "the weight form is for 16-bit samples, LINEAR and CUBIC");
+	static_assert(!FAST || (sizeof(S) == 2 && TAPS == 4), "the weight form is for 16-bit samples, CUBIC");
 	constexpr int SB = (int)sizeof(S);
 	constexpr int PB = NCH * SB;                          /* bytes per pixel                       */
 	constexpr int NW = 2 * PB / 4;                        /* dwords per pixel pair                 */
@@ -338,7 +320,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 	uint32_t wcol[2][2];                                  /* byte offset in a row of the sample (or pair) this lane fetches */
 	int      sel[2][2];                                   /* PAIRWIN: which pixel of the fetched pair is window column 2 * lane + j */
 	double   fx[2][2];
-	double   wx[(FAST && T == 4) ? 2 : 1][2][4];          /* FAST, CUBIC: the horizontal weights of my two columns */
+	double   wx[FAST ? 2 : 1][2][4];                      /* FAST: the horizontal weights of my two columns */
 #pragma unroll
 	for (int c = 0; c < 2; ++c) {
 		/* T == 1 (NONE): the one tap is the nearest source column, scale() of fix-ca.c:799-809 */
@@ -353,7 +335,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				const double xd = map_dbl(xx, g.xc, W, g.s[c], g.xs[c]);
 				c0 = (int)floor(xd);
 				fx[c][j] = __dsub_rn(xd, (double)c0);
-				if constexpr (FAST && T == 4) cr_weights(fx[c][j], wx[c][j]);
+				if constexpr (FAST) cr_weights(fx[c][j], wx[c][j]);
 			}
 			const int b = max(0, min(c0 - BACK - Uw, WIDE_WIN - T));              /* the planner guarantees the range */
 			hb[c][j] = (lds_xp)&xbuf[c * WIDE_WIN] + b;
@@ -416,8 +398,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				double p[T];
 #pragma unroll
 				for (int t = 0; t < T; ++t) p[t] = hb[c][j][t];
-				if constexpr (FAST && T == 4) out[j] = fma(wx[c][j][3], p[3], fma(wx[c][j][2], p[2], fma(wx[c][j][1], p[1], wx[c][j][0] * p[0])));
-				else if constexpr (FAST) out[j] = fma(fx[c][j], p[1] - p[0], p[0]);      /* LINEAR: s0 + fx (s1 - s0) on the integer samples */
+				if constexpr (FAST) out[j] = fma(wx[c][j][3], p[3], fma(wx[c][j][2], p[2], fma(wx[c][j][1], p[1], wx[c][j][0] * p[0])));
 				else out[j] = hfilter<T>(p, fx[c][j]);
 			}
 		}
@@ -575,12 +556,10 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 #pragma unroll
 					for (int c = 0; c < 2; ++c) {
 						double wy[4];
-						if constexpr (T == 4) cr_weights(sfy[k][c], wy);
+						cr_weights(sfy[k][c], wy);
 #pragma unroll
 						for (int j = 0; j < 2; ++j) {
-							double xv;
-							if constexpr (T == 4) xv = fma(wy[3], hh[c][j][3], fma(wy[2], hh[c][j][2], fma(wy[1], hh[c][j][1], wy[0] * hh[c][j][0])));
-							else xv = fma(sfy[k][c], hh[c][j][1] - hh[c][j][0], hh[c][j][0]);     /* h0 + fy (h1 - h0) */
+							double xv = fma(wy[3], hh[c][j][3], fma(wy[2], hh[c][j][2], fma(wy[1], hh[c][j][1], wy[0] * hh[c][j][0])));
 							xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
 							const double fr = __builtin_amdgcn_fract(xv);
 							outv[c][j] = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
@@ -592,10 +571,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 						while (redo) {
 							const int q = __builtin_ctz(redo);
 							redo &= redo - 1;
-							const int ex = min(x + (q & 1), W - 1), ey = Y0 + min(r, nrows - 1);
-							S e;
-							if constexpr (T == 4) e = exact_cubic_sample<S, NCH>(src, g, ex, ey, q >> 1);
-							else e = exact_linear_sample<S, NCH>(src, g, ex, ey, q >> 1);
+							const S e = exact_cubic_sample<S, NCH>(src, g, min(x + (q & 1), W - 1), Y0 + min(r, nrows - 1), q >> 1);
 #pragma unroll
 							for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -722,19 +698,6 @@ k_wcol_weights(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, Wide
 {
 	wcol_tile<S, NCH, 4, Q, ODDW, true>(src, dst, g, wp);
 }
-/* 16-bit LINEAR in the weight form: s0 + fx (s1 - s0) across columns, h0 + fy (h1 - h0) across rows, on the integer
- * samples: 4 fused multiply-adds per sample instead of 4 divisions and 10 operations.  The reference's value differs from
- * it by rounding errors only: 4 quotients s / 65535, 3 + 3 + 4 operations on values <= 2 and the final multiplication,
- * each <= 2^-53 relative: |x_ref - x| < 15 * 2.2e-16 * 65535 = 2.2e-10 samples, the weight form's own error < 4 * 2^-53
- * * 65535 = 3e-11.  Same rule as CUBIC: round as the reference rounds, recompute operation for operation
- * (exact_linear_sample) what lies within WIDE_FAST_EPS of a rounding boundary.  tests/c/weightbound.c measures the
- * difference of the two forms; the planner keeps the reference's order where boundaries are common (shifts by halves). */
-template <typename S, int NCH, int Q, bool ODDW>
-__global__ __launch_bounds__(64) void
-k_wlin_weights(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
-{
-	wcol_tile<S, NCH, 2, Q, ODDW, true>(src, dst, g, wp);
-}
 
 /* the instantiation a geometry runs: sample type x (interpolation, samples per pixel, odd width); `fast`: the weight
  * form with exact recomputation (16-bit samples, CUBIC, when the planner allows it) */
@@ -749,10 +712,6 @@ const void *wcol_kernel(int sel, bool fast)
 	constexpr int Q4 = sizeof(S) == 2 ? WIDE_SLOTS : WIDE_Q_WIDE, Q3 = sizeof(S) == 2 ? WIDE_SLOTS - 1 : WIDE_Q_WIDE;
 	if constexpr (sizeof(S) == 2) {
 		if (fast) switch (sel) {
-		case 7:  return reinterpret_cast<const void *>(&k_wlin_weights<S, 4, Q4, true>);
-		case 6:  return reinterpret_cast<const void *>(&k_wlin_weights<S, 4, Q4, false>);
-		case 5:  return reinterpret_cast<const void *>(&k_wlin_weights<S, 3, Q3, true>);
-		case 4:  return reinterpret_cast<const void *>(&k_wlin_weights<S, 3, Q3, false>);
 		case 11: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, 2, true>);
 		case 10: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, 2, false>);
 		case 9:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, 2, true>);
