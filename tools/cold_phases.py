@@ -12,7 +12,7 @@ with open(src, "wb") as f:
     f.write(b"P7\nWIDTH %d\nHEIGHT %d\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA\nENDHDR\n" % (W, H))
     f.write(synth.noise_bytes(0xF1CA1000, W * H * 4).tobytes())
 cli = os.path.join(ROOT, "gimp-fix-ca_amd", "fixca_cli")
-for extra in ([], ["--pinned"]) + ([sys.argv[1:]] if len(sys.argv) > 1 else []):
+for extra in [[], ["--pinned"]] + ([sys.argv[1:]] if len(sys.argv) > 1 else []):
     for k in range(int(os.environ.get("COLD_RUNS", "4"))):
         env = dict(os.environ, FIXCA_PHASES="1", FIXCA_T0_NS=str(time.clock_gettime_ns(time.CLOCK_MONOTONIC)))
         t = time.perf_counter()

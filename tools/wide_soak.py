@@ -1,4 +1,4 @@
-"""GPU box: soak of k_wcol's 16-bit CUBIC weight form against the one-thread-per-pixel fp64 kernel: N random parameter
+"""GPU box: soak of k_wcol's 16-bit weight forms (CUBIC, or LINEAR with SOAK_INTERP=1) against the one-thread-per-pixel fp64 kernel: N random parameter
 sets (lateral amounts up to the plug-in's +-30, lens anywhere, some with directional shifts) on 6000x4000 RGBA / RGB u16
 images of four kinds (noise, smooth ramps, ramps with a little noise, random 0 / 65535 steps).  Every sample must be identical.
 usage: wide_soak.py [N]"""
@@ -31,7 +31,7 @@ for it in range(N):
     kw = dict(blue=float(rng.uniform(-mag, mag)), red=float(rng.uniform(-mag, mag)), lens_x=float(rng.integers(-1, W + 1)), lens_y=float(rng.integers(-1, H + 1)))
     if it % 5 == 0:
         kw.update(x_blue=float(rng.uniform(-mag, mag)), y_red=float(rng.uniform(-mag, mag)))
-    p = fixca.make_params(interpolation=2, **kw)
+    p = fixca.make_params(interpolation=int(os.environ.get("SOAK_INTERP", "2")), **kw)
     desc = fixca.plan(W, H, nch * 2, 2, p)[1]
     weights_runs += "weights+recheck" in desc
     a = torch.zeros_like(raw); b = torch.zeros_like(raw)
