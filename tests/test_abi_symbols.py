@@ -163,12 +163,16 @@ def test_gimp_box_binding(tmp_path):
     new = open(work, encoding="utf-8").read().split("\n")
     import difflib
     ops = [op for op in difflib.SequenceMatcher(None, old, new, autojunk=False).get_opcodes() if op[0] != "equal"]
-    assert [op[0] for op in ops] == ["insert", "insert"] and len(new) == len(old) + 6      # two insertions, nothing removed or changed
+    assert [op[0] for op in ops] == ["insert", "insert"] and len(new) == len(old) + 2 + 8   # two insertions, nothing removed or changed
     i_inc = new.index("#include <fixca_hip.h>")
     assert "gimpui.h" in new[i_inc - 2]
     i_call = next(i for i, l in enumerate(new) if "fixca_region_host" in l)
-    assert new[i_call - 2].strip() == "{"                       # first statement of the definition ...
-    assert any("fix_ca_region" in l for l in new[i_call - 8:i_call - 2])      # ... of fix_ca_region
+    # right behind the statement that opens the progress bar, inside the definition of fix_ca_region, before its row buffers
+    assert any("gimp_progress_init" in l for l in new[i_call - 4:i_call])
+    i_def = max(i for i, l in enumerate(new[:i_call]) if "fix_ca_region" in l and l.lstrip().startswith("static"))
+    assert "{" in [l.strip() for l in new[i_def:i_def + 6]]                  # the definition, not the prototype
+    assert not any(l.startswith("}") for l in new[i_def:i_call])             # still inside that function
+    assert "gimp_progress_update (1.0)" in "\n".join(new[i_call:i_call + 6])  # the bar is filled before returning
     assert sum("fixca_region_host" in l for l in new) == 1
     # running it twice changes nothing more
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gimp_box", "apply_binding.py"), str(work), root])
