@@ -204,7 +204,8 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
         raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
-    assert ("move-none" if interp == 0 else "wide-roll") in fixca.plan(w, h, nch * sb, bpc, p)[1]
+    want = "move-none" if interp == 0 else "ring-linear" if (interp == 1 and nch == 4 and bpc != 2) else "wide-roll"
+    assert want in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
     for _ in range(2):       # twice: the second launch runs against warm caches, other timing
         fixca.fix_ca_region(raw, a, w, h, nch * sb, bpc, p, 0, w, 0, h, True, fixca.KERNEL_AUTO)
@@ -319,7 +320,10 @@ def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
                        (2, dict(lens_x=w // 2, lens_y=h // 2, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0))):
         p = fixca.make_params(interpolation=interp, **kw)
         kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
-        assert kid == (1 if (bpc == -8 and interp == 1 and nch == 3) else 7), desc
+        if interp == 1 and nch == 4 and bpc != 2:
+            assert kid in (7, 9), desc                      # the LDS-ring LINEAR kernel where its window fits
+        else:
+            assert kid == (1 if (bpc == -8 and interp == 1 and nch == 3) else 7), desc
         ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
         src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
         dst = torch.zeros_like(src)
@@ -377,6 +381,56 @@ def test_move_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, shape):
     assert took >= 12
 
 
+@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("shape", [(158, 61), (363, 140), (1202, 77), (244, 300), (2050, 33)], ids=str)
+def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, shape):
+    """k_lin (fixca_lin.hip): LINEAR on RGBA u32 / float / double (u16 on request) through the LDS ring, the reference's
+    bilinear arithmetic in fp64 operation for operation: the oracle's bytes, for ring rows of 1, 2 and 4 KiB, short and
+    tall tiles, row ranges, edge clamping (lens in a corner, shifts off the image), floats outside [0, 1] (clipped in
+    LINEAR, fix-ca.c:893) and an odd width for u16 (half a unit at the end of a row)"""
+    torch = torch_cuda
+    w, h = shape
+    if bpc != 2 and w % 2:
+        w += 1
+    sb, nch = abs(bpc), 4
+    img = _wide_image(dtype, w, h, nch, 5100 + abs(bpc) + w)
+    src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+    monkeypatch.setenv("FIXCA_LIN_U16", "1")
+    took = 0
+    for pi, kw in enumerate(MOVE_PARAMS):
+        p = fixca.make_params(interpolation=1, **_scaled(kw, w, h))
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc).view(np.uint8).reshape(h, w, nch * sb)
+        for nu, th in ((0, 0), (1, 7), (2, 64), (4, 200)):
+            monkeypatch.setenv("FIXCA_MOVE_NU", str(nu))
+            monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
+            kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
+            if pi in (0, 2, 3):
+                assert kid == 9, desc
+            took += kid == 9
+            dst = torch.full_like(src, 0x3C)
+            fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+            part = torch.full_like(src, 0x5A)
+            fixca.fix_ca_region(src, part, w, h, nch * sb, bpc, p, 0, w, 9, h - 4, True)
+            torch.cuda.synchronize()
+            assert dst.cpu().numpy().tobytes() == ref.tobytes(), (desc, kw)
+            got = part.cpu().numpy()
+            assert got[9:h - 4].tobytes() == ref[9:h - 4].tobytes(), (desc, kw)
+            assert np.all(got[:9] == 0x5A) and np.all(got[h - 4:] == 0x5A)
+    assert took >= 12
+    # a batch of images in one launch
+    if bpc == -4:
+        p = fixca.make_params(interpolation=1, **_scaled(MOVE_PARAMS[0], w, h))
+        imgs = [_wide_image(dtype, w, h, nch, 5200 + k) for k in range(5)]
+        srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]
+        dsts = [torch.zeros_like(t) for t in srcs]
+        monkeypatch.delenv("FIXCA_TH", raising=False)
+        monkeypatch.setenv("FIXCA_MOVE_NU", "0")
+        fixca.fix_ca_batch(srcs, dsts, w, h, nch * sb, bpc, p)
+        torch.cuda.synchronize()
+        for a, d in zip(imgs, dsts):
+            assert d.cpu().numpy().tobytes() == pyoracle.region(a, pyoracle.make_params(**p.as_dict()), bpc=bpc).tobytes()
+
+
 @pytest.mark.parametrize("idx", range(24))
 def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
     """random geometries and parameters (the 8-bit fuzz set) on the wide sample types: whatever kernel
@@ -406,7 +460,7 @@ def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
         got = dst.cpu().numpy()
         assert got[y1:y2].tobytes() == ref.view(np.uint8).reshape(h, w, nch * sb)[y1:y2].tobytes(), (desc, kw)
         assert np.all(got[:y1] == 0x6B) and np.all(got[y2:] == 0x6B)
-    assert seen <= {1, 7, 8}
+    assert seen <= {1, 7, 8, 9}
 
 
 @pytest.mark.parametrize("nch", [3, 4])
