@@ -683,13 +683,20 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	const int span = scan_row_span(g, 2);
 	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
 	const int step = (pb % 16 == 0) ? 1 : 2;
+	/* Launch shapes measured on MI355X, 6000x4000, one allocation per format (profiles/r03_sweep_r3k.txt; k_wcol on the
+	 * same buffers: float 53.1 %, u32 54.3 %, double 64.3 % of the HBM peak; nt copy 65-70 %):
+	 *   one image per launch: float 2-KiB rows x 200 rows (980 waves), 10 rows in flight 65.9 % (1-KiB rows x 200: 62.9,
+	 *     x 400: 46.0); u32 (three more fp64 operations per sample: more waves) 1-KiB rows x 200 rows (2000 waves) 61.2 %,
+	 *     2-KiB rows 55.7; double 2-KiB rows x 400 rows (1000 waves), 6 in flight 72.7 % (x 200 rows, 5 in flight: 51.3);
+	 *   many images per launch: 1-KiB rows x 32 rows, 8 in flight: float 69.9 %, u32 64.7 %, double 73.2 %. */
+	const bool integer = g->bpc > 0;
 	int nu = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	if (nu == 0) nu = (pb <= 16) ? 1 : 2;
+	if (nu == 0) nu = (batch || integer) ? 1 : 2;
 	if (nu == 3) nu = 2;
 	for (; nu >= 1; nu >>= 1) {
 		const int winb = nu * 1024;
 		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
-		if (depth == 0) depth = batch ? 8 : (10 * 1024 + winb - 1) / winb;
+		if (depth == 0) depth = batch ? 8 : (pb >= 32) ? 6 : 10;
 		if (depth < 2) depth = 2;
 		int ring = env_int("FIXCA_RING", 0, 0, 96);
 		if (ring == 0) {
@@ -714,8 +721,8 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		if (batch) {
 			th = 32;
 		} else {
-			/* the kernel has fp64 work to cover (40 operations per 4-byte pixel): one wave per SIMD and more */
-			const int want = 2048;
+			/* the kernel has fp64 work to cover (40 operations per 4-byte pixel): one wave per SIMD, two for u32 */
+			const int want = integer ? 2048 : 1024;
 			int chunks = (want + pl->nstrips / 2) / pl->nstrips;
 			if (chunks < 1) chunks = 1;
 			th = (rows + chunks - 1) / chunks;
