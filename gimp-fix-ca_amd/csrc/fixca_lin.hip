@@ -1,5 +1,5 @@
 /*
- * fixca_lin.hip — LINEAR on RGBA images of the wide sample types (u32, float, double; u16 on request) in the
+ * fixca_lin.hip — LINEAR on RGBA and RGB images of the wide sample types (u32, float, double; RGBA u16 on request) in the
  * structure of the NONE mover (fixca_move.hip): an LDS-DMA ring of raw source rows, 16-byte units per lane, nt stores,
  * with the reference's bilinear arithmetic (fix-ca.c:882-894, get_pixel / set_pixel :713-774) in fp64, operation for
  * operation: bit-identical to the CPU oracle.
@@ -15,8 +15,10 @@
  * coupling to the stores), each fetched once per wave for all its consumers (identity copy, both rows of the red and
  * of the blue interpolation).
  *
- *  - a lane owns NU 16-byte units of the strip's output row: one pixel (4-byte samples), half a pixel (double: red
- *    and green, or blue and alpha) or two pixels (u16);
+ *  - a lane owns NU 16-byte units of the strip's output row.  RGBA: one pixel (4-byte samples), half a pixel (double:
+ *    red and green, or blue and alpha) or two pixels (u16), red and blue at fixed places, green and alpha from the
+ *    unit's own 16 bytes.  RGB: units straddle pixels; every sample of a unit runs the same code with per-lane rows,
+ *    offsets and fractions, green samples keep their bits;
  *  - per computed sample: column c0 = floor(x'), c1 = c0 + 1 clamped (fix-ca.c:1170-1177), fraction fx: per-lane
  *    constants of the tile (the column map depends on the column only); per output row and channel: r0 = floor(y'),
  *    r1 clamped (fix-ca.c:1149-1158), fy: wave-uniform, from a per-64-rows table read with v_readlane;
@@ -50,16 +52,22 @@ __device__ __forceinline__ double lin_readlane_f64(double v, int l)
 	return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
-template <typename S, int NU>          /* S: sample type; NU: KiB per ring row = units per lane and row */
+template <typename S, int NCH, int NU>  /* S: sample type; NCH: 3 RGB, 4 RGBA; NU: KiB per ring row = units per lane and row */
 __global__ __launch_bounds__(64) void
 k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
 	typedef Codec<S> C;
 	constexpr int SB = (int)sizeof(S);
-	constexpr int PB = 4 * SB;                         /* RGBA                                          */
+	constexpr int PB = NCH * SB;
+	constexpr int NS = 16 / SB;                        /* samples per unit                              */
 	constexpr int WINB = NU * 1024;
-	constexpr int NC = (SB == 2) ? 4 : (SB == 4) ? 2 : 1;      /* samples computed per unit: (R0 B0 R1 B1) / (R B) / (R | B) */
+	/* samples computed per unit.  RGBA: the red and blue ones, at fixed places of the unit: (R0 B0 R1 B1) / (R B) /
+	 * (R | B: a double unit is half a pixel).  RGB: a unit straddles pixels and the channel of its sample k depends on
+	 * the unit modulo 3: every sample goes through the same code with per-lane rows, offsets and fractions, and a
+	 * green one (own row, own column, fractions 0) keeps its bits. */
+	constexpr int NC = (NCH == 3) ? NS : (SB == 2) ? 4 : (SB == 4) ? 2 : 1;
+	constexpr bool PERLANE = NCH == 3 || SB == 8;      /* a computed sample's channel differs between lanes */
 
 	const int lane = threadIdx.x;
 	const int W = g.W, H = g.H;
@@ -81,7 +89,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	int lo = X0;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lo = min(lo, (int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])));
-	constexpr int CA = (PB % 16 == 0) ? 1 : 2;         /* u16 RGBA: 8-byte pixels                       */
+	constexpr int CA = (PB % 16 == 0) ? 1 : (PB % 8 == 0) ? 2 : (PB % 4 == 0) ? 4 : 8;     /* columns per 16 bytes of row */
 	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(CA - 1));
 
 	/* ---- per-lane constants ---------------------------------------------------------------------------------------- */
@@ -90,22 +98,35 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	uint32_t off0[NU][NC], off1[NU][NC];               /* byte offsets in a ring row of the two taps' samples             */
 	double   fx[NU][NC];
 	uint32_t idoff[NU], stoff[NU];
-	int      blue[NU];                                 /* double: this unit holds (B, A), not (R, G)                      */
+	int      chan[NU][NC];                             /* PERLANE: 0 red, 1 blue, 2 green (copied)                        */
 #pragma unroll
 	for (int i = 0; i < NU; ++i) {
 		const int U = min(lane + 64 * i, nunits - 1);
 		idoff[i] = (uint32_t)((X0 - U0) * PB + 16 * U);
-		blue[i] = (SB == 8) ? (U & 1) : 0;
 #pragma unroll
 		for (int j = 0; j < NC; ++j) {
-			const int c = (SB == 8) ? blue[i] : (j & 1);                     /* 0 red, 1 blue */
-			const int px = min(X0 + ((SB == 8) ? U / 2 : (SB == 4) ? U : 2 * U + j / 2), W - 1);
-			const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
-			const int c0 = (int)floor(xd);
-			const int c1 = (c0 == W - 1) ? c0 : c0 + 1;                      /* fix-ca.c:1170-1177 */
-			fx[i][j] = __dsub_rn(xd, (double)c0);
-			off0[i][j] = (uint32_t)((c0 - U0) * PB + 2 * c * SB);
-			off1[i][j] = (uint32_t)((c1 - U0) * PB + 2 * c * SB);
+			int c, px;
+			if constexpr (NCH == 3) {
+				const int s = U * NS + j;                                    /* sample index from the strip's first pixel */
+				px = X0 + s / 3;
+				c = (s % 3 == 0) ? 0 : (s % 3 == 2) ? 1 : 2;
+			} else {
+				c = (SB == 8) ? (U & 1) : (j & 1);
+				px = X0 + ((SB == 8) ? U / 2 : (SB == 4) ? U : 2 * U + j / 2);
+			}
+			px = min(px, W - 1);
+			chan[i][j] = c;
+			if (c == 2) {                                                    /* green: its own sample, no interpolation */
+				fx[i][j] = 0.0;
+				off0[i][j] = off1[i][j] = (uint32_t)((px - U0) * PB + SB);
+			} else {
+				const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
+				const int c0 = (int)floor(xd);
+				const int c1 = (c0 == W - 1) ? c0 : c0 + 1;                  /* fix-ca.c:1170-1177 */
+				fx[i][j] = __dsub_rn(xd, (double)c0);
+				off0[i][j] = (uint32_t)((c0 - U0) * PB + 2 * c * SB);
+				off1[i][j] = (uint32_t)((c1 - U0) * PB + 2 * c * SB);
+			}
 		}
 	}
 
@@ -199,20 +220,23 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		u32x4 out[NU];
 #pragma unroll
 		for (int i = 0; i < NU; ++i) {
-			u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
+			u32x4 v = u32x4{ 0u, 0u, 0u, 0u };
+			if constexpr (NCH == 4) v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
 			S res[NC];
 #pragma unroll
 			for (int j = 0; j < NC; ++j) {
 				uint32_t a0, a1;
 				double wy, wy1;
-				if constexpr (SB == 8) {
-					a0 = blue[i] ? b0[1] : b0[0]; a1 = blue[i] ? b1[1] : b1[0];
-					wy = blue[i] ? fy[1] : fy[0]; wy1 = blue[i] ? omfy[1] : omfy[0];
+				if constexpr (PERLANE) {
+					const int c = chan[i][j];
+					a0 = (c == 0) ? b0[0] : (c == 1) ? b0[1] : bI; a1 = (c == 0) ? b1[0] : (c == 1) ? b1[1] : bI;
+					wy = (c == 0) ? fy[0] : (c == 1) ? fy[1] : 0.0; wy1 = (c == 0) ? omfy[0] : (c == 1) ? omfy[1] : 1.0;
 				} else {
 					a0 = b0[j & 1]; a1 = b1[j & 1];
 					wy = fy[j & 1]; wy1 = omfy[j & 1];
 				}
-				const double p00 = C::get(*reinterpret_cast<const S *>(ring + a0 + off0[i][j]));
+				const S s00 = *reinterpret_cast<const S *>(ring + a0 + off0[i][j]);
+				const double p00 = C::get(s00);
 				const double p10 = C::get(*reinterpret_cast<const S *>(ring + a0 + off1[i][j]));
 				const double p01 = C::get(*reinterpret_cast<const S *>(ring + a1 + off0[i][j]));
 				const double p11 = C::get(*reinterpret_cast<const S *>(ring + a1 + off1[i][j]));
@@ -220,8 +244,20 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 				const double a = __dadd_rn(p00, __dmul_rn(fx[i][j], __dsub_rn(p10, p00)));
 				const double b = __dadd_rn(p01, __dmul_rn(fx[i][j], __dsub_rn(p11, p01)));
 				res[j] = C::put(clip01(__dadd_rn(__dmul_rn(wy1, a), __dmul_rn(wy, b))));
+				if constexpr (NCH == 3) res[j] = (chan[i][j] == 2) ? s00 : res[j];       /* green is copied, never clipped (fix-ca.c:1098) */
 			}
-			if constexpr (SB == 2) {
+			if constexpr (NCH == 3) {
+				if constexpr (SB == 4) {
+					v.x = __builtin_bit_cast(uint32_t, res[0]); v.y = __builtin_bit_cast(uint32_t, res[1]);
+					v.z = __builtin_bit_cast(uint32_t, res[2]); v.w = __builtin_bit_cast(uint32_t, res[3]);
+				} else if constexpr (SB == 8) {
+					const unsigned long long q0 = __builtin_bit_cast(unsigned long long, res[0]), q1 = __builtin_bit_cast(unsigned long long, res[1]);
+					v.x = (uint32_t)q0; v.y = (uint32_t)(q0 >> 32); v.z = (uint32_t)q1; v.w = (uint32_t)(q1 >> 32);
+				} else {
+					v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16); v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
+					v.z = (uint32_t)res[4] | ((uint32_t)res[5] << 16); v.w = (uint32_t)res[6] | ((uint32_t)res[7] << 16);
+				}
+			} else if constexpr (SB == 2) {
 				v.x = (v.x & 0xFFFF0000u) | (uint32_t)res[0]; v.y = (v.y & 0xFFFF0000u) | (uint32_t)res[1];
 				v.z = (v.z & 0xFFFF0000u) | (uint32_t)res[2]; v.w = (v.w & 0xFFFF0000u) | (uint32_t)res[3];
 			} else if constexpr (SB == 4) {
@@ -253,26 +289,36 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	}
 }
 
-template <typename S>
+template <typename S, int NCH>
 const void *lin_kernel_nu(int nu)
 {
 	switch (nu) {
-	case 1:  return reinterpret_cast<const void *>(&k_lin<S, 1>);
-	case 2:  return reinterpret_cast<const void *>(&k_lin<S, 2>);
-	default: return reinterpret_cast<const void *>(&k_lin<S, 4>);
+	case 1:  return reinterpret_cast<const void *>(&k_lin<S, NCH, 1>);
+	case 2:  return reinterpret_cast<const void *>(&k_lin<S, NCH, 2>);
+	default: return reinterpret_cast<const void *>(&k_lin<S, NCH, 4>);
 	}
 }
 
 const void *lin_kernel_for(const FixcaGeom *g, int nu)
 {
-	if (g->nch != 4) return nullptr;
-	switch (g->bpc) {
-	case 2:  return lin_kernel_nu<uint16_t>(nu);
-	case 4:  return lin_kernel_nu<uint32_t>(nu);
-	case -4: return lin_kernel_nu<float>(nu);
-	case -8: return lin_kernel_nu<double>(nu);
-	default: return nullptr;
+	if (g->nch == 4) {
+		switch (g->bpc) {
+		case 2:  return lin_kernel_nu<uint16_t, 4>(nu);
+		case 4:  return lin_kernel_nu<uint32_t, 4>(nu);
+		case -4: return lin_kernel_nu<float, 4>(nu);
+		case -8: return lin_kernel_nu<double, 4>(nu);
+		default: return nullptr;
+		}
 	}
+	if (g->nch == 3) {
+		switch (g->bpc) {
+		case 4:  return lin_kernel_nu<uint32_t, 3>(nu);
+		case -4: return lin_kernel_nu<float, 3>(nu);
+		case -8: return lin_kernel_nu<double, 3>(nu);
+		default: return nullptr;
+		}
+	}
+	return nullptr;
 }
 
 }   /* namespace */

@@ -673,7 +673,8 @@ static bool lin_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 
 static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	if (g->interp != 1 || g->nch != 4 || g->bpc == 1) return false;
+	if (g->interp != 1 || g->bpc == 1) return false;
+	if (g->nch == 3 && g->bpc == 2) return false;        /* RGB u16: k_wcol (6-byte pixels, 8 quotients per unit) */
 	/* 16-bit samples: 4 samples per unit, 16 quotients and 70 operations per unit and row put the fp64 floor above the
 	 * memory time; k_wcol's rolling window does less arithmetic and stays (FIXCA_LIN_U16=1 to measure) */
 	if (g->bpc == 2 && !fixca_debug_flag("FIXCA_LIN_U16")) return false;
@@ -682,7 +683,7 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	if (pitch % 4) return false;
 	const int span = scan_row_span(g, 2);
 	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
-	const int step = (pb % 16 == 0) ? 1 : 2;
+	const int step = (pb % 16 == 0) ? 1 : (pb % 8 == 0) ? 2 : (pb % 4 == 0) ? 4 : 8;
 	/* Launch shapes measured on MI355X, 6000x4000, one allocation per format (profiles/r03_sweep_r3k.txt; k_wcol on the
 	 * same buffers: float 53.1 %, u32 54.3 %, double 64.3 % of the HBM peak; nt copy 65-70 %):
 	 *   one image per launch: float 2-KiB rows x 200 rows (980 waves), 10 rows in flight 65.9 % (1-KiB rows x 200: 62.9,
