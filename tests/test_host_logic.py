@@ -163,3 +163,71 @@ def test_bench_launcher_relays_the_ranks_exit_code(repo_root):
     r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+# ---- planner of the LDS-ring kernels of the wide sample types (k_move: NONE, k_lin: LINEAR); no GPU needed ----------
+
+def _plan_fields(desc):
+    f = dict(kv.split("=") for kv in desc.split() if "=" in kv)
+    ring, nu = f["ring"].rstrip("K").split("x")
+    return dict(oc=int(f["oc"]), th=int(f["th"]), ring=int(ring), nu=int(nu), depth=int(f["depth"]), strips=int(f["strips"]),
+                chunks=int(f["chunks"]), waves=int(f["waves"]), bpp=int(f["bpp"]))
+
+
+@pytest.mark.parametrize("bpc,nch", [(2, 4), (2, 3), (4, 4), (-4, 4), (-4, 3), (-8, 4), (-8, 3)], ids=str)
+@pytest.mark.parametrize("interp", [0, 1])
+def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
+    """k_move takes NONE on every wide format whose rows are whole dwords, k_lin LINEAR on RGBA u32 / float / double
+    and RGB double; strips are whole 16-byte units and whole pixels; a one-image launch is ONE generation (never more
+    waves than the ring's LDS footprint leaves slots); the batch hint changes the shape, not the kernel"""
+    sb = abs(bpc)
+    pb = nch * sb
+    for w, h, kw in ((6000, 4000, dict(blue=2.0, red=-2.0, lens_x=658, lens_y=1280)), (1202, 300, dict(blue=0.4, red=-0.3, lens_x=1000, lens_y=30, x_blue=-3.0, y_red=2.0)),
+                     (8192, 8192, dict(lens_x=4096, lens_y=4096, x_blue=1.0, y_blue=-7.5, y_red=4.0))):
+        p = fixca.make_params(interpolation=interp, **kw)
+        kid, desc = fixca.plan(w, h, pb, bpc, p)
+        kidb, descb = fixca.plan(w, h, pb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
+        if interp == 0:
+            assert kid == 8 and kidb == 8, desc
+        elif (nch == 4 and bpc != 2) or (nch == 3 and bpc == -8):
+            assert kid == 9 and kidb == 9, desc
+        else:
+            assert kid == 7 and kidb == 7, desc              # 16-bit and RGB 4-byte LINEAR stay with the rolling kernel
+            continue
+        for d in (desc, descb):
+            f = _plan_fields(d)
+            assert f["bpp"] == pb and f["nu"] in (1, 2, 4) and 1 <= f["depth"] <= 14
+            assert (f["oc"] * pb) % 16 == 0                          # whole units and whole pixels
+            assert f["oc"] * pb <= 64 * f["nu"] * 16                  # 64 lanes x nu units
+            assert f["strips"] == -(-w // f["oc"]) and f["waves"] == f["strips"] * f["chunks"]
+            assert f["ring"] * f["nu"] * 1024 <= 64 * 1024
+            assert f["ring"] >= f["depth"] + 2
+        f = _plan_fields(desc)
+        slots = min(16, (160 * 1024) // (f["ring"] * f["nu"] * 1024 + 64)) * 256
+        assert f["waves"] <= slots, desc                             # one generation
+        assert _plan_fields(descb)["th"] in (32, 64)                 # many images per launch: short tiles
+
+
+def test_ring_kernel_plans_fall_back():
+    """what the ring kernels refuse goes to the kernels that can: RGB u16 rows of odd width are not whole dwords
+    (k_wcol's halfword path), shifts beyond a ring row's reach fall back to the one-thread-per-pixel kernel, and the
+    debug switches select the round-2 paths for A/B runs"""
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=100, lens_y=50, interpolation=0)
+    assert fixca.plan(257, 193, 6, 2, p)[0] == 7                     # RGB u16, odd width
+    assert fixca.plan(258, 193, 6, 2, p)[0] == 8
+    # a scale far from 1: the ring kernel narrows its strips until every strip's window fits a ring row (k_wcol, whose
+    # per-channel windows are 128 columns, gives up on this one: tests/test_abi_symbols.py)
+    far = fixca.make_params(blue=-29.0, red=29.0, lens_x=600, lens_y=8, interpolation=1)
+    kid, desc = fixca.plan(1200, 16, 16, -4, far)
+    assert kid == 9 and _plan_fields(desc)["oc"] < 124, desc        # 2-KiB rows hold 128 columns of RGBA float: 80-column strips here
+    import os
+    os.environ["FIXCA_NO_MOVE"] = "1"
+    try:
+        assert fixca.plan(6000, 4000, 8, 2, p)[0] == 7 and fixca.plan(6000, 4000, 16, -4, p)[0] == 1
+    finally:
+        del os.environ["FIXCA_NO_MOVE"]
+    os.environ["FIXCA_NO_LIN"] = "1"
+    try:
+        assert fixca.plan(6000, 4000, 16, -4, fixca.make_params(blue=2.0, red=-2.0, lens_x=100, lens_y=50, interpolation=1))[0] == 7
+    finally:
+        del os.environ["FIXCA_NO_LIN"]
