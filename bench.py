@@ -131,6 +131,7 @@ def sample_bytes(bpc):
 KID_ROLL = 6                     # fixca_plan_describe's id of the row-rolling kernel (include/fixca_hip.h)
 KID_MOVE = 8                     # ... of the NONE byte mover of the wide sample types: up to 32 images per launch
 KID_LIN = 9                      # ... of the LDS-ring LINEAR kernel of the wide RGBA formats: likewise
+KID_CUB = 10                     # ... of the LDS-ring CUBIC kernel of the wide RGBA formats: likewise
 
 
 def kernel_name(kid, plan_text):
@@ -142,7 +143,7 @@ def kernel_name(kid, plan_text):
         rgb = "bpp=3" in words
         return "k_roll%s<%d,%s>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false")
     return {"exact-fp64": "k_exact/k_wide", "fast-none": "k_none", "fast-interp": "k_interp", "scan": "k_scan", "scanw": "k_scanw",
-            "wide-roll-fp64": "k_wcol", "move-none": "k_move", "ring-linear-fp64": "k_lin"}.get(words[0], words[0])
+            "wide-roll-fp64": "k_wcol", "move-none": "k_move", "ring-linear-fp64": "k_lin", "ring-cubic-fp64": "k_cub"}.get(words[0], words[0])
 
 
 def make_images(torch, fixca, n, h, w, c, bpc, seed0, dev):
@@ -212,7 +213,7 @@ def run_configs(torch, fixca, dev, per_launch):
                 dt = torch.float32 if bpc == -4 else torch.float64
                 md = float((dsts[0].view(dt).to(torch.float64) - exact.view(dt).to(torch.float64)).abs().max())
             # the row-rolling kernel (plan id 6) takes up to per_launch images in one launch, the NONE mover (8) up to 32; every other kernel is one launch per image
-            ipl = min(n, per_launch) if kid == KID_ROLL else min(n, 32) if kid in (KID_MOVE, KID_LIN) else 1
+            ipl = min(n, per_launch) if kid == KID_ROLL else min(n, 32) if kid in (KID_MOVE, KID_LIN, KID_CUB) else 1
             entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc), "images_per_launch": ipl, "launches_timed": reps * ((n + ipl - 1) // ipl),
                           "us_per_image": round(us, 2), "GBs": round(algo / us / 1e3, 1),
                           "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4), "mpix_s": round(w * h / us, 1),

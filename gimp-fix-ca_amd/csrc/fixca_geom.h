@@ -35,9 +35,9 @@ struct FixcaPlan {
 	int nblocks;        /* workgroups, padded to a multiple of 8 (256 threads
 	                       for kernels 2,3; one 64-thread wave for kernel 4)  */
 	int ring;           /* kernels 4, 6, 8: source rows in the LDS ring         */
-	int nu;             /* kernels 8, 9: KiB per ring row = 16-byte units a lane moves per output row (1, 2, 4) */
-	int depth;          /* kernels 8, 9: source rows kept in flight beyond the newest row in use */
-	int wide_fast;      /* kernel 7, 16-bit samples, CUBIC: the weight form with exact recomputation of the
+	int nu;             /* kernels 8, 9, 10: KiB per ring row = 16-byte units a lane moves per output row (1, 2, 4) */
+	int depth;          /* kernels 8, 9, 10: source rows kept in flight beyond the newest row in use */
+	int wide_fast;      /* kernels 7, 10, 16-bit samples, CUBIC: the weight form with exact recomputation of the
 	                       samples near a rounding boundary (fixca_wide.hip); 0 = operation for operation */
 };
 
@@ -50,6 +50,7 @@ struct FixcaPlan {
 #define FIXCA_K_WCOL    7   /* u16 / u32 / float / double samples: fp64 rolling window (fixca_wide.hip) */
 #define FIXCA_K_MOVE    8   /* u16 / u32 / float / double samples, NONE: LDS-ring byte mover (fixca_move.hip) */
 #define FIXCA_K_LIN     9   /* RGBA u32 / float / double (u16 on request), LINEAR: LDS ring + fp64 bilinear (fixca_lin.hip) */
+#define FIXCA_K_CUB     10  /* RGBA u16 / u32 / float / double, CUBIC: LDS ring + per-lane rolling window (fixca_cub.hip) */
 
 #define FIXCA_WAVE_COLS 256   /* 64 lanes x 4 pixels                           */
 

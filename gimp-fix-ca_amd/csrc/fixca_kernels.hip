@@ -722,6 +722,7 @@ extern "C" hipError_t fixca_launch_roll_rgb(const void *, void *, const FixcaGeo
 extern "C" hipError_t fixca_launch_wide(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_move(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_lin(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_cub(const void *, void *, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 
 extern "C" hipError_t
 fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
@@ -762,6 +763,8 @@ fixca_launch(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan
 		return fixca_launch_move(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_LIN:
 		return fixca_launch_lin(d_src, d_dst, g, pl, stream);
+	case FIXCA_K_CUB:
+		return fixca_launch_cub(d_src, d_dst, g, pl, stream);
 	case FIXCA_K_ROLL:
 		return g->bpp == 3 ? fixca_launch_roll_rgb(d_src, d_dst, g, pl, stream) : fixca_launch_roll(d_src, d_dst, g, pl, stream);
 	default:

@@ -41,6 +41,8 @@
 
 namespace {
 using fixca_codec::Codec;
+using fixca_codec::cr_weights;
+using fixca_codec::exact_cubic_sample;
 
 /* ---- pixel moves -------------------------------------------------------------------------------
  * Pixels travel as dwords through raw buffer loads / stores (descriptor = the image for loads, the
@@ -141,52 +143,6 @@ __device__ __forceinline__ double vfilter(const double (&h)[TAPS], double fy)
 {
 	if constexpr (TAPS == 4) return cr_exact(h[0], h[1], h[2], h[3], fy);              /* cubicX, fix-ca.c:916-918 */
 	else return __dadd_rn(__dmul_rn(__dsub_rn(1.0, fy), h[0]), __dmul_rn(fy, h[1]));     /* fix-ca.c:891, outer */
-}
-
-__device__ __forceinline__ int tap_index_rt(int c0, int t, int n) { return max(0, min(c0 - 1 + t, n - 1)); }   /* cubic taps, see tap_index */
-/* ---- 16-bit samples, CUBIC: the same results from a quarter of the arithmetic ---------------------
- * The reference's value of a sample is v = cubicX(cubicY(row 0..3)) on p = s / 65535, then round(clip(v) * 65535)
- * (fix-ca.c:896-920, 748-761): 38 fp64 operations in a fixed order plus 16 divisions.  In real arithmetic v * 65535 is
- * x = sum_t wy_t(fy) * sum_i wx_i(fx) * s_ti with the Catmull-Rom weights below, 8 fused multiply-adds on the integer
- * samples.  The two differ only by rounding errors: every one of the reference's 19 + 19 operations and 16 divisions
- * rounds a value of magnitude <= 12 (in units of p) by <= 2^-53 relative, the second filter multiplies the first one's
- * errors by at most sum |w| <= 1.5, so |x_ref - x| <= (230 + 1.5 * 230 + 16) * 12 * 1.2e-16 * 65535 = 5.6e-8 samples
- * (a worst-case bound: every operation at full magnitude with errors of one sign), and the weight form's own error is
- * below 1e-9 (measured over 6e7 random, extreme-step and nearly flat windows, numpy against the operation-for-operation
- * form: 9.8e-11; tests/c/weightbound.c measures a largest difference of 8.4e-11 between the two forms and asserts
- * < 1e-8).  The rounded sample can differ only when a rounding boundary k + 0.5 lies between the two values (clipping
- * to [0, 65535] moves both to the same integer): so x is rounded as the reference rounds, and the rare sample whose
- * fraction is within WIDE_FAST_EPS = 1e-6 of 0.5 (18 x the analytic bound, 10^4 x the measured difference) is
- * recomputed operation for operation from the source image (exact_cubic_sample, the one-thread-per-pixel kernel's
- * code).  The planner (plan_wide) keeps the operation-for-operation variant for geometries whose fractions sit on a
- * coarse dyadic grid (pure shifts by halves or quarters), where such samples are common. */
-#define WIDE_FAST_EPS 1e-6
-static_assert(WIDE_FAST_EPS >= 10 * 5.6e-8, "the recheck band must stay at least 10 x the analytic bound on |x_ref - x|");
-__device__ __forceinline__ void cr_weights(double t, double (&w)[4])
-{
-	const double t2 = t * t, t3 = t2 * t;
-	w[0] = 0.5 * (-t3 + 2.0 * t2 - t);
-	w[1] = 0.5 * (3.0 * t3 - 5.0 * t2 + 2.0);
-	w[2] = 0.5 * (-3.0 * t3 + 4.0 * t2 + t);
-	w[3] = 0.5 * (t3 - t2);
-}
-/* one output sample of channel c (0 red, 1 blue) at (x, y), operation for operation (fix-ca.c:1260-1318) */
-template <typename S, int NCH>
-__device__ __forceinline__ S exact_cubic_sample(const S *__restrict__ src, const FixcaGeom &g, int x, int y, int c)
-{
-	typedef Codec<S> C;
-	const size_t pitch = (size_t)g.W * NCH;
-	const double yd = map_dbl(y, g.yc, g.H, g.s[c], g.ys[c]), xd = map_dbl(x, g.xc, g.W, g.s[c], g.xs[c]);
-	const int r0 = (int)floor(yd), c0 = (int)floor(xd);
-	const double fy = __dsub_rn(yd, (double)r0), fx = __dsub_rn(xd, (double)c0);
-	double h[4];
-#pragma unroll
-	for (int t = 0; t < 4; ++t) {
-		const S *row = src + (size_t)tap_index_rt(r0, t, g.H) * pitch + 2 * c;
-		h[t] = cr_exact(C::get(row[(size_t)tap_index_rt(c0, 0, g.W) * NCH]), C::get(row[(size_t)tap_index_rt(c0, 1, g.W) * NCH]),
-		                C::get(row[(size_t)tap_index_rt(c0, 2, g.W) * NCH]), C::get(row[(size_t)tap_index_rt(c0, 3, g.W) * NCH]), fx);
-	}
-	return C::put(clip01(cr_exact(h[0], h[1], h[2], h[3], fy)));
 }
 
 /* tap t of the window that starts at integer coordinate c0, clamped as the reference clamps it:

@@ -188,7 +188,7 @@ def _fuzz_cases(n, seed):
     return cases
 
 
-@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0),
+@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (4, 4, 2), (2, 3, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0),
                                             (4, 4, 0), (-4, 3, 0), (-8, 4, 0), (-8, 3, 0)], ids=str)
 def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
     """k_wcol against the one-thread-per-pixel kernel (itself checked against the oracle above) on BASELINE's
@@ -204,7 +204,8 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
         raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
-    want = "move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2 and (nch == 4 or bpc == -8)) else "wide-roll"
+    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2 and (nch == 4 or bpc == -8))
+            else "ring-cubic" if (interp == 2 and nch == 4) else "wide-roll")
     assert want in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
     for _ in range(2):       # twice: the second launch runs against warm caches, other timing
@@ -322,6 +323,8 @@ def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
         kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
         if interp == 1 and bpc != 2:
             assert kid in (1, 7, 9), desc                   # the LDS-ring LINEAR kernel where its window fits
+        elif nch == 4:
+            assert kid in (7, 10), desc                     # ... and the LDS-ring CUBIC kernel on RGBA
         else:
             assert kid == 7, desc
         ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc)
@@ -434,6 +437,50 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
             assert d.cpu().numpy().tobytes() == pyoracle.region(a, pyoracle.make_params(**p.as_dict()), bpc=bpc).tobytes()
 
 
+@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("shape", [(158, 61), (363, 140), (1202, 77), (244, 300), (2050, 33)], ids=str)
+def test_ring_cubic_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, shape):
+    """k_cub (fixca_cub.hip): CUBIC on RGBA u16 / u32 / float / double through the LDS ring with a rolling window per
+    lane: the oracle's bytes for ring rows of 1, 2 and 4 KiB, tiles of 7 rows (rebuilds dominate) to 200, row ranges,
+    scale steps of the row map inside tiles (repeated and skipped source rows: the window is rebuilt), windows clamped
+    at all four image edges, floats outside [0, 1], odd widths; 16-bit samples in the weight form with exact
+    recomputation (forced on half-pixel shifts, where rounding boundaries are everywhere) and, with FIXCA_WCOL_REF, not
+    at all (k_wcol takes them)"""
+    torch = torch_cuda
+    w, h = shape
+    if bpc != 2 and w % 2:
+        w += 1
+    sb, nch = abs(bpc), 4
+    img = _wide_image(dtype, w, h, nch, 6100 + abs(bpc) + w)
+    src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+    took = 0
+    cases = MOVE_PARAMS + [dict(lens_x=0.5, lens_y=0.5, x_blue=0.5, y_red=-0.5), dict(blue=-12.0, red=14.0, lens_x=0.2, lens_y=0.9)]
+    for pi, kw in enumerate(cases):
+        p = fixca.make_params(interpolation=2, **_scaled(kw, w, h))
+        ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc).view(np.uint8).reshape(h, w, nch * sb)
+        monkeypatch.setenv("FIXCA_WCOL_WEIGHTS", "1") if (bpc == 2 and pi == 4) else monkeypatch.delenv("FIXCA_WCOL_WEIGHTS", raising=False)
+        for nu, th in ((0, 0), (1, 7), (2, 64), (4 if bpc != 2 else 2, 200)):
+            monkeypatch.setenv("FIXCA_MOVE_NU", str(nu))
+            monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
+            kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
+            if pi in (0, 2, 3):
+                assert kid == 10, desc
+            took += kid == 10
+            dst = torch.full_like(src, 0x3C)
+            fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
+            part = torch.full_like(src, 0x5A)
+            fixca.fix_ca_region(src, part, w, h, nch * sb, bpc, p, 0, w, 9, h - 4, True)
+            torch.cuda.synchronize()
+            assert dst.cpu().numpy().tobytes() == ref.tobytes(), (desc, kw)
+            got = part.cpu().numpy()
+            assert got[9:h - 4].tobytes() == ref[9:h - 4].tobytes(), (desc, kw)
+            assert np.all(got[:9] == 0x5A) and np.all(got[h - 4:] == 0x5A)
+    assert took >= 12
+    if bpc == 2:
+        monkeypatch.setenv("FIXCA_WCOL_REF", "1")
+        assert fixca.plan(w, h, nch * sb, bpc, fixca.make_params(interpolation=2, **_scaled(MOVE_PARAMS[0], w, h)))[0] == 7
+
+
 @pytest.mark.parametrize("idx", range(24))
 def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
     """random geometries and parameters (the 8-bit fuzz set) on the wide sample types: whatever kernel
@@ -463,7 +510,7 @@ def test_fuzz_wide_samples_against_oracle(torch_cuda, idx):
         got = dst.cpu().numpy()
         assert got[y1:y2].tobytes() == ref.view(np.uint8).reshape(h, w, nch * sb)[y1:y2].tobytes(), (desc, kw)
         assert np.all(got[:y1] == 0x6B) and np.all(got[y2:] == 0x6B)
-    assert seen <= {1, 7, 8, 9}
+    assert seen <= {1, 7, 8, 9, 10}
 
 
 @pytest.mark.parametrize("nch", [3, 4])
@@ -488,7 +535,7 @@ def test_wide_weights_kernel_recomputes_boundary_samples(torch_cuda, nch, monkey
             if force:
                 monkeypatch.setenv(force, "1")
             kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
-            assert kid == 7
+            assert kid == 7 or (kid == 10 and nch == 4), desc       # RGBA: the ring kernel runs the weight form, k_wcol the reference order
             weights = "weights+recheck" in desc
             assert weights == (force == "FIXCA_WCOL_WEIGHTS" or (force == "" and kw.get("blue", 0.0) == 2.0)), (desc, kw, force)
             dst = torch.zeros_like(src)

@@ -175,7 +175,7 @@ def _plan_fields(desc):
 
 
 @pytest.mark.parametrize("bpc,nch", [(2, 4), (2, 3), (4, 4), (-4, 4), (-4, 3), (-8, 4), (-8, 3)], ids=str)
-@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("interp", [0, 1, 2])
 def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
     """k_move takes NONE on every wide format whose rows are whole dwords, k_lin LINEAR on RGBA u32 / float / double
     and RGB double; strips are whole 16-byte units and whole pixels; a one-image launch is ONE generation (never more
@@ -189,7 +189,10 @@ def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
         kidb, descb = fixca.plan(w, h, pb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
         if interp == 0:
             assert kid == 8 and kidb == 8, desc
-        elif (nch == 4 and bpc != 2) or (nch == 3 and bpc == -8):
+        elif interp == 2 and nch == 4:
+            assert kid == 10 and kidb == 10, desc
+            assert ("weights+recheck" in desc) == (bpc == 2)
+        elif interp == 1 and ((nch == 4 and bpc != 2) or (nch == 3 and bpc == -8)):
             assert kid == 9 and kidb == 9, desc
         else:
             assert kid == 7 and kidb == 7, desc              # 16-bit and RGB 4-byte LINEAR stay with the rolling kernel
