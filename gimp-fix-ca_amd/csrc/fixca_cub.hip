@@ -1,17 +1,16 @@
 /*
- * fixca_cub.hip — CUBIC on RGBA images of the wide sample types (u16, u32, float, double) in the structure of the
- * NONE mover and of k_lin (fixca_move.hip, fixca_lin.hip): an LDS-DMA ring of raw source rows, 16-byte units per
- * lane, nt stores; the reference's Catmull-Rom arithmetic (cubicY across columns, cubicX across rows, fix-ca.c:896-920;
- * get_pixel / set_pixel :713-774) in fp64, operation for operation: bit-identical to the CPU oracle.
+ * fixca_cub.hip — CUBIC on RGBA float and double images in the structure of the NONE mover and of k_lin
+ * (fixca_move.hip, fixca_lin.hip): an LDS-DMA ring of raw source rows, 16-byte units per lane, nt stores; the
+ * reference's Catmull-Rom arithmetic (cubicY across columns, cubicX across rows, fix-ca.c:896-920; get_pixel /
+ * set_pixel :713-774) in fp64, operation for operation: bit-identical to the CPU oracle.
  *
  * k_wcol (fixca_wide.hip) does the same arithmetic; what differs is how the data moves.  k_wcol shares every
  * converted source sample across the wave through LDS and holds its loads in a register queue two rows ahead: a wave
- * that waits for its stores to be acknowledged has nothing else in flight, and the kernels sit at 45-62 % of the
- * HBM roofline with the write stream not overlapping.  Here source rows arrive by LDS-DMA `depth` rows
- * ahead (no registers, no coupling to the stores), and each lane works for itself:
+ * that waits for its stores to be acknowledged has nothing else in flight.  Here source rows arrive by LDS-DMA
+ * `depth` rows ahead (no registers, no coupling to the stores), and each lane works for itself:
  *
- *  - a lane owns NU 16-byte units of the strip's output row: one pixel (4-byte samples), half a pixel (double) or two
- *    pixels (u16): 2, 1 or 4 computed samples per unit;
+ *  - a lane owns NU 16-byte units of the strip's output row: one pixel (float: red and blue computed) or half a
+ *    pixel (double: red, or blue);
  *  - per computed sample the 4 tap columns clamp(c0 - 1 + t) (fix-ca.c:1270-1298) are per-lane ring offsets for the
  *    whole tile, with the fraction fx;
  *  - a ROLLING WINDOW PER LANE: the 4 horizontally filtered rows of every computed sample live in registers (8 doubles
@@ -21,11 +20,13 @@
  *    map that repeats or skips a row) the windows are rebuilt from the ring: the rows are clamp(y0 - 1 + t)
  *    (fix-ca.c:1218-1256), and clamping is monotone, so the slide is valid at the image edges too.  Re-using the value
  *    of an expression is not a change of rounding: every operation sees the operands the reference's would.
- *  - 16-bit samples: the weight form of fixca_wide.hip (k_wcol_weights): both filters as fused multiply-adds on the
- *    integer samples, x rounded as the reference rounds, and every sample whose fraction is within WIDE_FAST_EPS of a
- *    rounding boundary recomputed operation for operation from the source image (exact_cubic_sample; the bound that
- *    makes this exact is derived in fixca_codec.h).  The planner keeps the reference's order for geometries whose
- *    fractions sit on a coarse dyadic grid (wide_fast_ok).
+ *
+ * Where it pays (measured against k_wcol on the same buffers, profiles/r03_sweep_r3o.txt): CUBIC is bound by its
+ * dependent fp64 chains (two cubics of 19 operations per sample), and a ring of 16 KiB per wave leaves 9 waves per CU
+ * where k_wcol runs 8-12 with four chains per lane.  RGBA double: 64.4 % of the HBM peak against 58.0 % (six images per
+ * launch), 60.0 against 58.0 (one image); RGBA float: 55.2 against 51.6 % batched, 48.7 against 52.1 one image per
+ * launch.  16-bit samples (also in the weight form) and u32 lose 2-8 points and stay with k_wcol: the planner
+ * (plan_cub) sends doubles here always and floats for batches.
  */
 #include "fixca_device.h"
 #include "fixca_codec.h"
@@ -55,17 +56,17 @@ __device__ __forceinline__ double cub_readlane_f64(double v, int l)
 }
 __device__ __forceinline__ int cub_clamp(int v, int n) { return max(0, min(v, n - 1)); }
 
-template <typename S, int NU, bool FAST>   /* FAST: 16-bit samples, the weight form with exact recomputation near rounding boundaries */
+template <typename S, int NU>
 __global__ __launch_bounds__(64) void
 k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
 	typedef Codec<S> C;
-	static_assert(!FAST || sizeof(S) == 2, "the weight form is for 16-bit samples");
+	static_assert(sizeof(S) == 4 || sizeof(S) == 8, "float and double (u32 compiles too); 16-bit samples stay with k_wcol");
 	constexpr int SB = (int)sizeof(S);
 	constexpr int PB = 4 * SB;                         /* RGBA                                          */
 	constexpr int WINB = NU * 1024;
-	constexpr int NC = (SB == 2) ? 4 : (SB == 4) ? 2 : 1;      /* samples computed per unit: (R0 B0 R1 B1) / (R B) / (R | B) */
+	constexpr int NC = (SB == 4) ? 2 : 1;              /* samples computed per unit: (R B) / (R | B)     */
 
 	const int lane = threadIdx.x;
 	const int W = g.W, H = g.H;
@@ -87,18 +88,15 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	int lo = X0;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lo = min(lo, cub_clamp((int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])) - 1, W));
-	constexpr int CA = (PB % 16 == 0) ? 1 : 2;
+	constexpr int CA = 1;                              /* 16- and 32-byte pixels: every column starts a unit */
 	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(CA - 1));
 
 	/* ---- per-lane constants ---------------------------------------------------------------------------------------- */
 	const int nunits = ((xe - X0) * PB + 15) >> 4;
-	const int tail_dw = (((xe - X0) * PB) & 15) >> 2;  /* u16 images of odd width: half a unit at the end of the row */
 	uint32_t off[NU][NC][4];                           /* byte offsets in a ring row of the 4 taps' samples              */
 	double   fx[NU][NC];
-	double   wx[FAST ? NU : 1][FAST ? NC : 1][4];      /* FAST: the horizontal Catmull-Rom weights                       */
 	uint32_t idoff[NU], stoff[NU];
 	int      blue[NU];                                 /* double: this unit holds (B, A), not (R, G)                     */
-	int      pxcol[NU][NC];                            /* FAST: the output column of the sample (for the recomputation)   */
 #pragma unroll
 	for (int i = 0; i < NU; ++i) {
 		const int U = min(lane + 64 * i, nunits - 1);
@@ -107,12 +105,10 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 		for (int j = 0; j < NC; ++j) {
 			const int c = (SB == 8) ? blue[i] : (j & 1);
-			const int px = min(X0 + ((SB == 8) ? U / 2 : (SB == 4) ? U : 2 * U + j / 2), W - 1);
-			pxcol[i][j] = px;
+			const int px = min(X0 + ((SB == 8) ? U / 2 : U), W - 1);
 			const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
 			const int c0 = (int)floor(xd);
 			fx[i][j] = __dsub_rn(xd, (double)c0);
-			if constexpr (FAST) fixca_codec::cr_weights(fx[i][j], wx[i][j]);
 #pragma unroll
 			for (int t = 0; t < 4; ++t)                                      /* fix-ca.c:1270-1298: clamp(c0 - 1 + t) */
 				off[i][j][t] = (uint32_t)((cub_clamp(c0 - 1 + t, W) - U0) * PB + 2 * c * SB);
@@ -146,9 +142,8 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 	for (int i = 0; i < NU; ++i) {
 		const int U = lane + 64 * i;
-		stoff[i] = (U < nunits - (tail_dw ? 1 : 0)) ? (uint32_t)(X0 * PB + 16 * U) : dst_bytes;
+		stoff[i] = (U < nunits) ? (uint32_t)(X0 * PB + 16 * U) : dst_bytes;
 	}
-	const int tail_u = (nunits - 1) >> 6, tail_lane = (nunits - 1) & 63;
 
 	/* ---- the ring (as in k_move) ---------------------------------------------------------------------------------------- */
 	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
@@ -190,10 +185,7 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		S s[4];
 #pragma unroll
 		for (int t = 0; t < 4; ++t) s[t] = *reinterpret_cast<const S *>(ring + base + off[i][j][t]);
-		if constexpr (FAST)
-			return fma(wx[i][j][3], (double)s[3], fma(wx[i][j][2], (double)s[2], fma(wx[i][j][1], (double)s[1], wx[i][j][0] * (double)s[0])));
-		else
-			return cr_exact(C::get(s[0]), C::get(s[1]), C::get(s[2]), C::get(s[3]), fx[i][j]);          /* fix-ca.c:905-907 */
+		return cr_exact(C::get(s[0]), C::get(s[1]), C::get(s[2]), C::get(s[3]), fx[i][j]);              /* fix-ca.c:905-907 */
 	};
 
 	double hh[NU][NC][4];                              /* the rolling windows: 4 horizontally filtered rows per computed sample */
@@ -239,48 +231,17 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		}
 		y0prev[0] = y0[0]; y0prev[1] = y0[1];
 
-		double wy[2][4];
-		if constexpr (FAST) { fixca_codec::cr_weights(fy[0], wy[0]); fixca_codec::cr_weights(fy[1], wy[1]); }
 		u32x4 out[NU];
 #pragma unroll
 		for (int i = 0; i < NU; ++i) {
 			u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
 			S res[NC];
-			uint32_t redo = 0;
 #pragma unroll
 			for (int j = 0; j < NC; ++j) {
-				const int c = (SB == 8) ? blue[i] : (j & 1);
-				if constexpr (FAST) {
-					const double (&w)[4] = wy[j & 1];
-					double xv = fma(w[3], hh[i][j][3], fma(w[2], hh[i][j][2], fma(w[1], hh[i][j][1], w[0] * hh[i][j][0])));
-					xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
-					const double fr = __builtin_amdgcn_fract(xv);
-					res[j] = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
-					redo |= (__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS ? 1u : 0u) << j;
-				} else {
-					const double f = (SB == 8) ? (c ? fy[1] : fy[0]) : fy[j & 1];
-					res[j] = C::put(clip01(cr_exact(hh[i][j][0], hh[i][j][1], hh[i][j][2], hh[i][j][3], f)));   /* fix-ca.c:916-919 */
-				}
+				const double f = (SB == 8) ? (blue[i] ? fy[1] : fy[0]) : fy[j & 1];
+				res[j] = C::put(clip01(cr_exact(hh[i][j][0], hh[i][j][1], hh[i][j][2], hh[i][j][3], f)));       /* fix-ca.c:916-919 */
 			}
-			if constexpr (FAST) {
-				if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0) != 0, 0)) {
-					/* a few samples per image: recomputed the reference's way from the source image */
-					while (redo) {
-						const int q = __builtin_ctz(redo);
-						redo &= redo - 1;
-						int col = pxcol[i][0];
-#pragma unroll
-						for (int j = 1; j < NC; ++j) col = (q == j) ? pxcol[i][j] : col;
-						const S e = fixca_codec::exact_cubic_sample<S, 4>(reinterpret_cast<const S *>(src), g, col, y, q & 1);
-#pragma unroll
-						for (int j = 0; j < NC; ++j) res[j] = (q == j) ? e : res[j];
-					}
-				}
-			}
-			if constexpr (SB == 2) {
-				v.x = (v.x & 0xFFFF0000u) | (uint32_t)res[0]; v.y = (v.y & 0xFFFF0000u) | (uint32_t)res[1];
-				v.z = (v.z & 0xFFFF0000u) | (uint32_t)res[2]; v.w = (v.w & 0xFFFF0000u) | (uint32_t)res[3];
-			} else if constexpr (SB == 4) {
+			if constexpr (SB == 4) {
 				v.x = __builtin_bit_cast(uint32_t, res[0]);
 				v.z = __builtin_bit_cast(uint32_t, res[1]);
 			} else {
@@ -293,40 +254,27 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 		for (int i = 0; i < NU; ++i)
 			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);
-		if (tail_dw) {
-#pragma unroll
-			for (int i = 0; i < NU; ++i)
-				if (i == tail_u) {
-					const bool mine = lane == tail_lane;
-					const uint32_t o = (uint32_t)(X0 * PB + 16 * (lane + 64 * i)) + so_st;
-#pragma unroll
-					for (int d = 0; d < 3; ++d)
-						if (d < tail_dw) __builtin_amdgcn_raw_buffer_store_b32(out[i][d], rs_dst, mine ? o + 4 * d : dst_bytes, 0, 2);
-				}
-		}
 		so_st += pitch;
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the next row's DMA may overwrite what was read here */
 	}
 }
 
-template <typename S, bool FAST>
+template <typename S>
 const void *cub_kernel_nu(int nu)
 {
 	switch (nu) {
-	case 1:  return reinterpret_cast<const void *>(&k_cub<S, 1, FAST>);
-	case 2:  return reinterpret_cast<const void *>(&k_cub<S, 2, FAST>);
-	default: return reinterpret_cast<const void *>(&k_cub<S, 4, FAST>);
+	case 1:  return reinterpret_cast<const void *>(&k_cub<S, 1>);
+	case 2:  return reinterpret_cast<const void *>(&k_cub<S, 2>);
+	default: return reinterpret_cast<const void *>(&k_cub<S, 4>);
 	}
 }
 
-const void *cub_kernel_for(const FixcaGeom *g, int nu, bool fast)
+const void *cub_kernel_for(const FixcaGeom *g, int nu)
 {
 	if (g->nch != 4) return nullptr;
 	switch (g->bpc) {
-	case 2:  return fast ? cub_kernel_nu<uint16_t, true>(nu) : cub_kernel_nu<uint16_t, false>(nu);
-	case 4:  return cub_kernel_nu<uint32_t, false>(nu);
-	case -4: return cub_kernel_nu<float, false>(nu);
-	case -8: return cub_kernel_nu<double, false>(nu);
+	case -4: return cub_kernel_nu<float>(nu);
+	case -8: return cub_kernel_nu<double>(nu);
 	default: return nullptr;
 	}
 }
@@ -339,12 +287,12 @@ fixca_launch_cub_batch(const void *const *d_src, void *const *d_dst, int n_image
 	if (g->y2 <= g->y1) return hipSuccess;
 	if (n_images < 1 || n_images > MOVE_BATCH_MAX) return hipErrorInvalidValue;
 	if (g->interp != 2 || (pl->nu != 1 && pl->nu != 2 && pl->nu != 4) || pl->depth < 1 || pl->depth > MOVE_DEPTH_MAX) return hipErrorInvalidValue;
-	const void *fn = cub_kernel_for(g, pl->nu, pl->wide_fast != 0);
+	const void *fn = cub_kernel_for(g, pl->nu);
 	if (!fn) return hipErrorInvalidValue;
 	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + 64;
 	if (lds > MOVE_LDS_MAX + 64) return hipErrorInvalidValue;
 	static std::mutex mu;
-	static const void *done[24];
+	static const void *done[8];
 	static int ndone = 0;
 	{
 		std::lock_guard<std::mutex> lock(mu);
@@ -352,7 +300,7 @@ fixca_launch_cub_batch(const void *const *d_src, void *const *d_dst, int n_image
 		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
 		if (!seen) {
 			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + 64);
-			if (ndone < 24) done[ndone++] = fn;
+			if (ndone < 8) done[ndone++] = fn;
 		}
 	}
 	MovePlan mp;

@@ -762,8 +762,6 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 
 /* ---- plan for CUBIC on the wide RGBA formats through the LDS ring (fixca_cub.hip) --------------- */
 
-static bool wide_fast_ok(const FixcaGeom *g);
-
 /* every strip's window: its own columns (green, alpha) and the four clamped taps of the red and of the blue filter */
 static bool cub_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 {
@@ -785,26 +783,27 @@ static bool cub_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 
 static bool plan_cub(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	if (g->interp != 2 || g->nch != 4 || g->bpc == 1) return false;
-	/* 16-bit samples: only in the weight form (4 + 4 fused multiply-adds per sample on the integer samples); where the
-	 * planner keeps the reference's operation order (shifts by halves: rounding boundaries are common) k_wcol's shared
-	 * conversions do less arithmetic */
-	const bool fast = g->bpc == 2 && wide_fast_ok(g);
-	if (g->bpc == 2 && !fast) return false;
+	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
+	/* Where the ring kernel beats k_wcol (profiles/r03_sweep_r3o.txt, one allocation per format): RGBA double always
+	 * (64.4 against 58.0 % of the HBM peak six images per launch, 60.0 against 58.0 one image), RGBA float in a batch
+	 * (55.2 against 51.6 %; one image per launch 48.7 against 52.1: k_wcol).  u16 (also in the weight form: 38-46
+	 * against 45 %) and u32 (43-48 against 51) stay with k_wcol; FIXCA_CUB_ALL=1 plans floats always (tests). */
+	if (g->interp != 2 || g->nch != 4) return false;
+	if (!(g->bpc == -8 || (g->bpc == -4 && (batch || fixca_debug_flag("FIXCA_CUB_ALL"))))) return false;
 	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
 	const long long pitch = (long long)W * pb;
 	if (pitch % 4) return false;
 	const int span = scan_row_span(g, 4);
-	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
-	const int step = (pb % 16 == 0) ? 1 : 2;
-	const bool integer = g->bpc > 0;
+	const int step = 1;
+	/* 1-KiB ring rows, 64-row tiles, many waves: the kernel is bound by its fp64 chains and wants occupancy, not fat waves
+	 * (2-KiB rows: 42.9 against 55.2 % for float; 400-row tiles of 2-KiB rows 52.3 against 60.0 % for double) */
 	int nu = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	if (nu == 0) nu = (batch || integer) ? 1 : 2;
+	if (nu == 0) nu = 1;
 	if (nu == 3) nu = 2;
 	for (; nu >= 1; nu >>= 1) {
 		const int winb = nu * 1024;
 		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
-		if (depth == 0) depth = batch ? 8 : (pb >= 24) ? 6 : 10;
+		if (depth == 0) depth = batch ? 8 : 6;
 		if (depth < 2) depth = 2;
 		int ring = env_int("FIXCA_RING", 0, 0, 96);
 		if (ring == 0) {
@@ -820,26 +819,12 @@ static bool plan_cub(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			if (cub_cols_fit(g, oc, winb)) oc_pick = oc;
 		if (!oc_pick) continue;
 		pl->kernel = FIXCA_K_CUB;
-		pl->wide_fast = fast ? 1 : 0;
 		pl->nu = nu;
 		pl->depth = depth;
 		pl->oc = oc_pick;
 		pl->ring = ring;
 		pl->nstrips = (W + oc_pick - 1) / oc_pick;
-		int th;
-		if (batch) {
-			th = 64;                                     /* a tile's first row builds the windows from 4 source rows and its halo is span rows */
-		} else {
-			const int want = integer ? 2048 : 1024;
-			int per_cu = (160 * 1024) / (ring * winb + 64);   /* one generation: never more waves than slots */
-			if (per_cu > 16) per_cu = 16;
-			if (per_cu < 1) per_cu = 1;
-			int chunks = (want + pl->nstrips / 2) / pl->nstrips;
-			if (chunks > per_cu * 256 / pl->nstrips) chunks = per_cu * 256 / pl->nstrips;
-			if (chunks < 1) chunks = 1;
-			th = (rows + chunks - 1) / chunks;
-			if (th < 32) th = 32;
-		}
+		const int th = 64;       /* a tile's first row builds its windows from 4 source rows, its halo is span rows: 32 rows lose 2 points, 128 rows 1-2 */
 		pl->th = env_int("FIXCA_TH", th, 1, 4096);
 		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * pitch > (1LL << 31)) {
 			const long long fit = (1LL << 31) / pitch - 2 * FIXCA_SOURCE_ROWS;
@@ -862,7 +847,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_NO_LIN", "FIXCA_NO_CUB", "FIXCA_LIN_U16", "FIXCA_LIN_RGB", "FIXCA_MOVE_NU", "FIXCA_MOVE_DEPTH", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_NO_LIN", "FIXCA_NO_CUB", "FIXCA_CUB_ALL", "FIXCA_LIN_U16", "FIXCA_LIN_RGB", "FIXCA_MOVE_NU", "FIXCA_MOVE_DEPTH", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH" };
 
 static void env_signature(char *buf, size_t n)
@@ -877,8 +862,8 @@ static void env_signature(char *buf, size_t n)
 
 int fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; int device; char env[320]; FixcaPlan pl; } last;
-	char env[320];
+	static thread_local struct { bool valid; FixcaGeom g; unsigned flags; int device; char env[352]; FixcaPlan pl; } last;
+	char env[352];
 	env_signature(env, sizeof env);
 	/* k_wcol's tile height is sized to the occupancy the CURRENT device reports (fixca_wide_slots): after
 	 * fixca_set_device() the plan of the previous device must not be handed out.  Only the wide LINEAR / CUBIC plans
@@ -972,7 +957,7 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 	else if (pl->kernel == FIXCA_K_MOVE || pl->kernel == FIXCA_K_LIN || pl->kernel == FIXCA_K_CUB)
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d ring=%dx%dK depth=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
 		         pl->oc, pl->th, pl->ring, pl->nu, pl->depth, pl->nstrips, pl->nchunks, pl->nwaves,
-		         (pl->kernel == FIXCA_K_CUB && pl->wide_fast) ? " weights+recheck" : "");
+		         "");
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

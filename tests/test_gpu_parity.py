@@ -205,7 +205,7 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
     want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2 and (nch == 4 or bpc == -8))
-            else "ring-cubic" if (interp == 2 and nch == 4) else "wide-roll")
+            else "ring-cubic" if (interp == 2 and nch == 4 and bpc == -8) else "wide-roll")
     assert want in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
     for _ in range(2):       # twice: the second launch runs against warm caches, other timing
@@ -437,33 +437,30 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
             assert d.cpu().numpy().tobytes() == pyoracle.region(a, pyoracle.make_params(**p.as_dict()), bpc=bpc).tobytes()
 
 
-@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("bpc,dtype", [(-4, np.float32), (-8, np.float64)], ids=lambda v: str(v))
 @pytest.mark.parametrize("shape", [(158, 61), (363, 140), (1202, 77), (244, 300), (2050, 33)], ids=str)
 def test_ring_cubic_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, shape):
-    """k_cub (fixca_cub.hip): CUBIC on RGBA u16 / u32 / float / double through the LDS ring with a rolling window per
-    lane: the oracle's bytes for ring rows of 1, 2 and 4 KiB, tiles of 7 rows (rebuilds dominate) to 200, row ranges,
-    scale steps of the row map inside tiles (repeated and skipped source rows: the window is rebuilt), windows clamped
-    at all four image edges, floats outside [0, 1], odd widths; 16-bit samples in the weight form with exact
-    recomputation (forced on half-pixel shifts, where rounding boundaries are everywhere) and, with FIXCA_WCOL_REF, not
-    at all (k_wcol takes them)"""
+    """k_cub (fixca_cub.hip): CUBIC on RGBA float / double through the LDS ring with a rolling window per lane: the
+    oracle's bytes for ring rows of 1, 2 and 4 KiB, tiles of 7 rows (rebuilds dominate) to 200, row ranges, scale steps
+    of the row map inside tiles (repeated and skipped source rows: the window is rebuilt), windows clamped at all four
+    image edges, floats outside [0, 1], odd widths.  (The planner sends floats here for batches only: FIXCA_CUB_ALL
+    routes the single calls of this test through it.)"""
     torch = torch_cuda
     w, h = shape
-    if bpc != 2 and w % 2:
-        w += 1
     sb, nch = abs(bpc), 4
     img = _wide_image(dtype, w, h, nch, 6100 + abs(bpc) + w)
     src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
+    monkeypatch.setenv("FIXCA_CUB_ALL", "1")
     took = 0
     cases = MOVE_PARAMS + [dict(lens_x=0.5, lens_y=0.5, x_blue=0.5, y_red=-0.5), dict(blue=-12.0, red=14.0, lens_x=0.2, lens_y=0.9)]
     for pi, kw in enumerate(cases):
         p = fixca.make_params(interpolation=2, **_scaled(kw, w, h))
         ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc).view(np.uint8).reshape(h, w, nch * sb)
-        monkeypatch.setenv("FIXCA_WCOL_WEIGHTS", "1") if (bpc == 2 and pi == 4) else monkeypatch.delenv("FIXCA_WCOL_WEIGHTS", raising=False)
-        for nu, th in ((0, 0), (1, 7), (2, 64), (4 if bpc != 2 else 2, 200)):
+        for nu, th in ((0, 0), (1, 7), (2, 64), (4, 200)):
             monkeypatch.setenv("FIXCA_MOVE_NU", str(nu))
             monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
             kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
-            if pi in (0, 2, 3):
+            if pi in (0, 2, 3, 4):
                 assert kid == 10, desc
             took += kid == 10
             dst = torch.full_like(src, 0x3C)
@@ -475,10 +472,20 @@ def test_ring_cubic_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, shape)
             got = part.cpu().numpy()
             assert got[9:h - 4].tobytes() == ref[9:h - 4].tobytes(), (desc, kw)
             assert np.all(got[:9] == 0x5A) and np.all(got[h - 4:] == 0x5A)
-    assert took >= 12
-    if bpc == 2:
-        monkeypatch.setenv("FIXCA_WCOL_REF", "1")
-        assert fixca.plan(w, h, nch * sb, bpc, fixca.make_params(interpolation=2, **_scaled(MOVE_PARAMS[0], w, h)))[0] == 7
+    assert took >= 16
+    # the batch entry (where floats take this kernel by themselves)
+    monkeypatch.delenv("FIXCA_CUB_ALL")
+    monkeypatch.delenv("FIXCA_TH", raising=False)
+    monkeypatch.setenv("FIXCA_MOVE_NU", "0")
+    p = fixca.make_params(interpolation=2, **_scaled(MOVE_PARAMS[0], w, h))
+    assert fixca.plan(w, h, nch * sb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)[0] == 10
+    imgs = [_wide_image(dtype, w, h, nch, 6200 + k) for k in range(3)]
+    srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]
+    dsts = [torch.zeros_like(t) for t in srcs]
+    fixca.fix_ca_batch(srcs, dsts, w, h, nch * sb, bpc, p)
+    torch.cuda.synchronize()
+    for a, d in zip(imgs, dsts):
+        assert d.cpu().numpy().tobytes() == pyoracle.region(a, pyoracle.make_params(**p.as_dict()), bpc=bpc).tobytes()
 
 
 @pytest.mark.parametrize("idx", range(24))

@@ -189,9 +189,10 @@ def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
         kidb, descb = fixca.plan(w, h, pb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
         if interp == 0:
             assert kid == 8 and kidb == 8, desc
-        elif interp == 2 and nch == 4:
-            assert kid == 10 and kidb == 10, desc
-            assert ("weights+recheck" in desc) == (bpc == 2)
+        elif interp == 2 and nch == 4 and bpc in (-4, -8):
+            assert kidb == 10 and kid == (10 if bpc == -8 else 7), desc      # floats: batches only
+            if kid != 10:
+                desc = descb
         elif interp == 1 and ((nch == 4 and bpc != 2) or (nch == 3 and bpc == -8)):
             assert kid == 9 and kidb == 9, desc
         else:
@@ -207,7 +208,8 @@ def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
             assert f["ring"] >= f["depth"] + 2
         f = _plan_fields(desc)
         slots = min(16, (160 * 1024) // (f["ring"] * f["nu"] * 1024 + 64)) * 256
-        assert f["waves"] <= slots, desc                             # one generation
+        if interp != 2:
+            assert f["waves"] <= slots, desc                         # the movers: one generation of fat waves
         assert _plan_fields(descb)["th"] in (32, 64)                 # many images per launch: short tiles
 
 
