@@ -23,9 +23,9 @@
  *
  * Where it pays (measured against k_wcol on the same buffers, profiles/r03_sweep_r3o.txt): CUBIC is bound by its
  * dependent fp64 chains (two cubics of 19 operations per sample), and a ring of 16 KiB per wave leaves 9 waves per CU
- * where k_wcol runs 8-12 with four chains per lane.  RGBA double: 64.4 % of the HBM peak against 58.0 % (six images per
- * launch), 60.0 against 58.0 (one image); RGBA float: 55.2 against 51.6 % batched, 48.7 against 52.1 one image per
- * launch.  16-bit samples (also in the weight form) and u32 lose 2-8 points and stay with k_wcol: the planner
+ * where k_wcol runs 8-12 with four chains per lane.  RGBA double: 64.5 % of the HBM peak against 58.0 % (six images per
+ * launch), 61.0 against 57.9 (one image); RGBA float: 55.6 against 51.2 % batched, 48.7 against 52.1 one image per
+ * launch (profiles/r03_sweep_r3p.txt).  16-bit samples (also in the weight form) and u32 lose 2-8 points and stay with k_wcol: the planner
  * (plan_cub) sends doubles here always and floats for batches.
  */
 #include "fixca_device.h"

@@ -785,8 +785,8 @@ static bool plan_cub(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
 	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
 	/* Where the ring kernel beats k_wcol (profiles/r03_sweep_r3o.txt, one allocation per format): RGBA double always
-	 * (64.4 against 58.0 % of the HBM peak six images per launch, 60.0 against 58.0 one image), RGBA float in a batch
-	 * (55.2 against 51.6 %; one image per launch 48.7 against 52.1: k_wcol).  u16 (also in the weight form: 38-46
+	 * (64.5 against 58.0 % of the HBM peak six images per launch, 61.0 against 57.9 one image), RGBA float in a batch
+	 * (55.6 against 51.2 %; one image per launch 48.7 against 52.1: k_wcol).  u16 (also in the weight form: 38-46
 	 * against 45 %) and u32 (43-48 against 51) stay with k_wcol; FIXCA_CUB_ALL=1 plans floats always (tests). */
 	if (g->interp != 2 || g->nch != 4) return false;
 	if (!(g->bpc == -8 || (g->bpc == -4 && (batch || fixca_debug_flag("FIXCA_CUB_ALL"))))) return false;
@@ -803,7 +803,9 @@ static bool plan_cub(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	for (; nu >= 1; nu >>= 1) {
 		const int winb = nu * 1024;
 		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
-		if (depth == 0) depth = batch ? 8 : 6;
+		/* few rows in flight: every KiB of ring is occupancy the fp64 chains need (double, six per launch: 4 rows in
+		 * flight 64.5 %, 8 rows 63.0, 12 rows 59.3; float 55.6 / 53.3 / 49.3) */
+		if (depth == 0) depth = 4;
 		if (depth < 2) depth = 2;
 		int ring = env_int("FIXCA_RING", 0, 0, 96);
 		if (ring == 0) {
@@ -824,7 +826,9 @@ static bool plan_cub(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		pl->oc = oc_pick;
 		pl->ring = ring;
 		pl->nstrips = (W + oc_pick - 1) / oc_pick;
-		const int th = 64;       /* a tile's first row builds its windows from 4 source rows, its halo is span rows: 32 rows lose 2 points, 128 rows 1-2 */
+		/* a tile's first row builds its windows from 4 source rows and its halo is span rows: in a batch 32 rows lose 2 points,
+		 * 128 rows 1-2; one image per launch (double): 48 rows 61.0 %, 64 rows 59.7, 96 rows 57.2 */
+		const int th = batch ? 64 : 48;
 		pl->th = env_int("FIXCA_TH", th, 1, 4096);
 		if ((long long)(pl->th + 2 * FIXCA_SOURCE_ROWS) * pitch > (1LL << 31)) {
 			const long long fit = (1LL << 31) / pitch - 2 * FIXCA_SOURCE_ROWS;
