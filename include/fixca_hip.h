@@ -78,7 +78,7 @@ FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
  * "512 images" configuration): image i is d_src[i] -> d_dst[i], all rows.  The
  * pointer arrays are host arrays of device pointers (read during the call, not kept).
  * Asynchronous on `stream`.  Launches: 8-bit samples through the row-rolling kernel take
- * up to 128 images per kernel launch, NONE (and LINEAR where kernel 9 runs) on the wider
+ * up to 128 images per kernel launch, NONE (and LINEAR / CUBIC where kernels 9 / 10 run) on the wider
  * sample types up to 32, every other kernel one image per launch, all back to back on `stream`.
  *
  * Stream capture: once a geometry's tables exist (one earlier call with the same size,
@@ -105,6 +105,7 @@ FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, i
  *   7 wide-roll-fp64  u16 / u32 / float / double, LINEAR and CUBIC, fp64 rolling window
  *   8 move-none       u16 / u32 / float / double, NONE: LDS-ring byte mover
  *   9 ring-linear-fp64 RGBA u32 / float / double and RGB double, LINEAR: LDS ring + fp64 bilinear
+ *  10 ring-cubic-fp64  RGBA double (and float in batches), CUBIC: LDS ring + a rolling window per lane
  * (5 is retired.)  Usable with no GPU: nothing is launched.  For LINEAR / CUBIC on the wide
  * sample types the planner asks the HIP runtime for the current device's occupancy (this
  * may initialise the runtime); without a device it plans for a 256-CU part.
