@@ -15,15 +15,20 @@
  * coupling to the stores), each fetched once per wave for all its consumers (identity copy, both rows of the red and
  * of the blue interpolation).
  *
- *  - a lane owns NU 16-byte units of the strip's output row.  RGBA: one pixel (4-byte samples), half a pixel (double:
- *    red and green, or blue and alpha) or two pixels (u16), red and blue at fixed places, green and alpha from the
- *    unit's own 16 bytes.  RGB: units straddle pixels; every sample of a unit runs the same code with per-lane rows,
- *    offsets and fractions, green samples keep their bits;
+ *  - a lane owns NU 16-byte units of the strip's output row: one pixel (4-byte samples), half a pixel (double: red
+ *    and green, or blue and alpha) or two pixels (u16);
  *  - per computed sample: column c0 = floor(x'), c1 = c0 + 1 clamped (fix-ca.c:1170-1177), fraction fx: per-lane
  *    constants of the tile (the column map depends on the column only); per output row and channel: r0 = floor(y'),
  *    r1 clamped (fix-ca.c:1149-1158), fy: wave-uniform, from a per-64-rows table read with v_readlane;
  *  - 4 LDS reads of a sample each, get_pixel, the two horizontal and the vertical interpolation in the reference's
  *    order, clip_d, set_pixel; green and alpha come with the unit's own 16 bytes.
+ *
+ * RGB (k_lin_rgb): 16-byte units straddle 12- and 24-byte pixels, so a unit's samples would change channel from lane to
+ * lane (tried: per-row selects of every sample's rows and fractions, green samples computed for nothing: slower than
+ * k_wcol on 4-byte samples).  Instead a lane owns 24 BYTES OF WHOLE PIXELS (two pixels of 4-byte samples, one of
+ * doubles): red and blue sit at fixed places, green is copied, and the wave's 1536 bytes of an output row are put
+ * together in LDS (each lane writes its 24 bytes) and read back as 16-byte units in lane order, so that the stores are
+ * the same full-KiB nt stores as everywhere.
  */
 #include "fixca_device.h"
 #include "fixca_codec.h"
@@ -52,22 +57,16 @@ __device__ __forceinline__ double lin_readlane_f64(double v, int l)
 	return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
-template <typename S, int NCH, int NU>  /* S: sample type; NCH: 3 RGB, 4 RGBA; NU: KiB per ring row = units per lane and row */
+template <typename S, int NU>          /* S: sample type; NU: KiB per ring row = units per lane and row */
 __global__ __launch_bounds__(64) void
 k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
 	typedef Codec<S> C;
 	constexpr int SB = (int)sizeof(S);
-	constexpr int PB = NCH * SB;
-	constexpr int NS = 16 / SB;                        /* samples per unit                              */
+	constexpr int PB = 4 * SB;                         /* RGBA                                          */
 	constexpr int WINB = NU * 1024;
-	/* samples computed per unit.  RGBA: the red and blue ones, at fixed places of the unit: (R0 B0 R1 B1) / (R B) /
-	 * (R | B: a double unit is half a pixel).  RGB: a unit straddles pixels and the channel of its sample k depends on
-	 * the unit modulo 3: every sample goes through the same code with per-lane rows, offsets and fractions, and a
-	 * green one (own row, own column, fractions 0) keeps its bits. */
-	constexpr int NC = (NCH == 3) ? NS : (SB == 2) ? 4 : (SB == 4) ? 2 : 1;
-	constexpr bool PERLANE = NCH == 3 || SB == 8;      /* a computed sample's channel differs between lanes */
+	constexpr int NC = (SB == 2) ? 4 : (SB == 4) ? 2 : 1;      /* samples computed per unit: (R0 B0 R1 B1) / (R B) / (R | B) */
 
 	const int lane = threadIdx.x;
 	const int W = g.W, H = g.H;
@@ -89,7 +88,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	int lo = X0;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lo = min(lo, (int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])));
-	constexpr int CA = (PB % 16 == 0) ? 1 : (PB % 8 == 0) ? 2 : (PB % 4 == 0) ? 4 : 8;     /* columns per 16 bytes of row */
+	constexpr int CA = (PB % 16 == 0) ? 1 : 2;         /* u16 RGBA: 8-byte pixels                       */
 	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(CA - 1));
 
 	/* ---- per-lane constants ---------------------------------------------------------------------------------------- */
@@ -98,35 +97,22 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	uint32_t off0[NU][NC], off1[NU][NC];               /* byte offsets in a ring row of the two taps' samples             */
 	double   fx[NU][NC];
 	uint32_t idoff[NU], stoff[NU];
-	int      chan[NU][NC];                             /* PERLANE: 0 red, 1 blue, 2 green (copied)                        */
+	int      blue[NU];                                 /* double: this unit holds (B, A), not (R, G)                      */
 #pragma unroll
 	for (int i = 0; i < NU; ++i) {
 		const int U = min(lane + 64 * i, nunits - 1);
 		idoff[i] = (uint32_t)((X0 - U0) * PB + 16 * U);
+		blue[i] = (SB == 8) ? (U & 1) : 0;
 #pragma unroll
 		for (int j = 0; j < NC; ++j) {
-			int c, px;
-			if constexpr (NCH == 3) {
-				const int s = U * NS + j;                                    /* sample index from the strip's first pixel */
-				px = X0 + s / 3;
-				c = (s % 3 == 0) ? 0 : (s % 3 == 2) ? 1 : 2;
-			} else {
-				c = (SB == 8) ? (U & 1) : (j & 1);
-				px = X0 + ((SB == 8) ? U / 2 : (SB == 4) ? U : 2 * U + j / 2);
-			}
-			px = min(px, W - 1);
-			chan[i][j] = c;
-			if (c == 2) {                                                    /* green: its own sample, no interpolation */
-				fx[i][j] = 0.0;
-				off0[i][j] = off1[i][j] = (uint32_t)((px - U0) * PB + SB);
-			} else {
-				const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
-				const int c0 = (int)floor(xd);
-				const int c1 = (c0 == W - 1) ? c0 : c0 + 1;                  /* fix-ca.c:1170-1177 */
-				fx[i][j] = __dsub_rn(xd, (double)c0);
-				off0[i][j] = (uint32_t)((c0 - U0) * PB + 2 * c * SB);
-				off1[i][j] = (uint32_t)((c1 - U0) * PB + 2 * c * SB);
-			}
+			const int c = (SB == 8) ? blue[i] : (j & 1);                     /* 0 red, 1 blue */
+			const int px = min(X0 + ((SB == 8) ? U / 2 : (SB == 4) ? U : 2 * U + j / 2), W - 1);
+			const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
+			const int c0 = (int)floor(xd);
+			const int c1 = (c0 == W - 1) ? c0 : c0 + 1;                      /* fix-ca.c:1170-1177 */
+			fx[i][j] = __dsub_rn(xd, (double)c0);
+			off0[i][j] = (uint32_t)((c0 - U0) * PB + 2 * c * SB);
+			off1[i][j] = (uint32_t)((c1 - U0) * PB + 2 * c * SB);
 		}
 	}
 
@@ -220,23 +206,20 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		u32x4 out[NU];
 #pragma unroll
 		for (int i = 0; i < NU; ++i) {
-			u32x4 v = u32x4{ 0u, 0u, 0u, 0u };
-			if constexpr (NCH == 4) v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
+			u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
 			S res[NC];
 #pragma unroll
 			for (int j = 0; j < NC; ++j) {
 				uint32_t a0, a1;
 				double wy, wy1;
-				if constexpr (PERLANE) {
-					const int c = chan[i][j];
-					a0 = (c == 0) ? b0[0] : (c == 1) ? b0[1] : bI; a1 = (c == 0) ? b1[0] : (c == 1) ? b1[1] : bI;
-					wy = (c == 0) ? fy[0] : (c == 1) ? fy[1] : 0.0; wy1 = (c == 0) ? omfy[0] : (c == 1) ? omfy[1] : 1.0;
+				if constexpr (SB == 8) {
+					a0 = blue[i] ? b0[1] : b0[0]; a1 = blue[i] ? b1[1] : b1[0];
+					wy = blue[i] ? fy[1] : fy[0]; wy1 = blue[i] ? omfy[1] : omfy[0];
 				} else {
 					a0 = b0[j & 1]; a1 = b1[j & 1];
 					wy = fy[j & 1]; wy1 = omfy[j & 1];
 				}
-				const S s00 = *reinterpret_cast<const S *>(ring + a0 + off0[i][j]);
-				const double p00 = C::get(s00);
+				const double p00 = C::get(*reinterpret_cast<const S *>(ring + a0 + off0[i][j]));
 				const double p10 = C::get(*reinterpret_cast<const S *>(ring + a0 + off1[i][j]));
 				const double p01 = C::get(*reinterpret_cast<const S *>(ring + a1 + off0[i][j]));
 				const double p11 = C::get(*reinterpret_cast<const S *>(ring + a1 + off1[i][j]));
@@ -244,20 +227,8 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 				const double a = __dadd_rn(p00, __dmul_rn(fx[i][j], __dsub_rn(p10, p00)));
 				const double b = __dadd_rn(p01, __dmul_rn(fx[i][j], __dsub_rn(p11, p01)));
 				res[j] = C::put(clip01(__dadd_rn(__dmul_rn(wy1, a), __dmul_rn(wy, b))));
-				if constexpr (NCH == 3) res[j] = (chan[i][j] == 2) ? s00 : res[j];       /* green is copied, never clipped (fix-ca.c:1098) */
 			}
-			if constexpr (NCH == 3) {
-				if constexpr (SB == 4) {
-					v.x = __builtin_bit_cast(uint32_t, res[0]); v.y = __builtin_bit_cast(uint32_t, res[1]);
-					v.z = __builtin_bit_cast(uint32_t, res[2]); v.w = __builtin_bit_cast(uint32_t, res[3]);
-				} else if constexpr (SB == 8) {
-					const unsigned long long q0 = __builtin_bit_cast(unsigned long long, res[0]), q1 = __builtin_bit_cast(unsigned long long, res[1]);
-					v.x = (uint32_t)q0; v.y = (uint32_t)(q0 >> 32); v.z = (uint32_t)q1; v.w = (uint32_t)(q1 >> 32);
-				} else {
-					v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16); v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-					v.z = (uint32_t)res[4] | ((uint32_t)res[5] << 16); v.w = (uint32_t)res[6] | ((uint32_t)res[7] << 16);
-				}
-			} else if constexpr (SB == 2) {
+			if constexpr (SB == 2) {
 				v.x = (v.x & 0xFFFF0000u) | (uint32_t)res[0]; v.y = (v.y & 0xFFFF0000u) | (uint32_t)res[1];
 				v.z = (v.z & 0xFFFF0000u) | (uint32_t)res[2]; v.w = (v.w & 0xFFFF0000u) | (uint32_t)res[3];
 			} else if constexpr (SB == 4) {
@@ -289,36 +260,237 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	}
 }
 
-template <typename S, int NCH>
+#define LIN_RGB_LANE_BYTES 24                       /* a lane's whole pixels: 2 x 12 bytes or 1 x 24 bytes */
+#define LIN_RGB_ROW_BYTES  (64 * LIN_RGB_LANE_BYTES)   /* 1536: the strip's output row, assembled in LDS */
+#define LIN_RGB_NU         2                        /* 2-KiB ring rows: 170 columns of RGB float, 85 of RGB double */
+
+template <typename S>                              /* u32, float, double */
+__global__ __launch_bounds__(64) void
+k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];     /* K ring rows, then the staging row */
+	typedef Codec<S> C;
+	constexpr int SB = (int)sizeof(S);
+	static_assert(SB == 4 || SB == 8, "RGB u16 stays with k_wcol");
+	constexpr int PB = 3 * SB;
+	constexpr int PXL = LIN_RGB_LANE_BYTES / PB;       /* pixels per lane: 2 or 1                       */
+	constexpr int NU = LIN_RGB_NU;
+	constexpr int WINB = NU * 1024;
+	constexpr int LW = LIN_RGB_LANE_BYTES / 4;         /* dwords a lane contributes to the row          */
+
+	const int lane = threadIdx.x;
+	const int W = g.W, H = g.H;
+	const int img = blockIdx.x / mp.nblocks;
+	const int tile = xcd_remap(blockIdx.x - img * mp.nblocks, mp.nblocks);
+	if (tile >= mp.nwaves) return;
+	const uint8_t *__restrict__ src = imgs.src[img];
+	uint8_t *__restrict__ dst = imgs.dst[img];
+	const int strip = tile % mp.nstrips, chunk = tile / mp.nstrips;
+	const int X0 = strip * mp.ocpx, xe = min(X0 + mp.ocpx, W);
+	const int Y0 = g.y1 + chunk * mp.th;
+	const int nrows = min(mp.th, g.y2 - Y0);
+	const uint32_t pitch = (uint32_t)W * PB;
+	const int K = mp.ring;
+	const uint32_t kmagic = (uint32_t)((0x100000000ull + (unsigned)K - 1) / (unsigned)K);
+	uint32_t *const stage = reinterpret_cast<uint32_t *>(ring + (size_t)K * WINB);
+
+	int lo = X0;
+#pragma unroll
+	for (int c = 0; c < 2; ++c) lo = min(lo, (int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])));
+	constexpr int CA = (PB % 8 == 0) ? 2 : 4;          /* columns per 16 bytes of row: the DMA's global address stays 16-byte aligned in the row */
+	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(CA - 1));
+
+	/* ---- per-lane constants: my pixels, the taps of their red and blue samples ---------------------------------------- */
+	const int nbytes = (xe - X0) * PB;
+	const int nunits = (nbytes + 15) >> 4;
+	const int tail_dw = (nbytes & 15) >> 2;
+	uint32_t off0[PXL][2], off1[PXL][2], goff[PXL];
+	double   fx[PXL][2];
+#pragma unroll
+	for (int j = 0; j < PXL; ++j) {
+		const int px = min(X0 + PXL * lane + j, W - 1);
+		goff[j] = (uint32_t)((px - U0) * PB + SB);                         /* my green sample */
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
+			const int c0 = (int)floor(xd);
+			const int c1 = (c0 == W - 1) ? c0 : c0 + 1;                      /* fix-ca.c:1170-1177 */
+			fx[j][c] = __dsub_rn(xd, (double)c0);
+			off0[j][c] = (uint32_t)((c0 - U0) * PB + 2 * c * SB);
+			off1[j][c] = (uint32_t)((c1 - U0) * PB + 2 * c * SB);
+		}
+	}
+	/* the units I read back from the staging row and store: unit lane, and unit 64 + lane for the first 32 lanes */
+	uint32_t stoff[2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+		const int U = lane + 64 * i;
+		stoff[i] = (U < nunits - (tail_dw ? 1 : 0)) ? (uint32_t)(X0 * PB + 16 * U) : 0xFFFFFFFFu;
+	}
+
+	int    r0_v[2] = { 0, 0 };
+	double fy_v[2] = { 0.0, 0.0 };
+	auto row_tables = [&](int rseg) {
+		const int y = min(Y0 + rseg + lane, g.y2 - 1);
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			const double yd = map_dbl(y, g.yc, H, g.s[c], g.ys[c]);
+			r0_v[c] = (int)floor(yd);
+			fy_v[c] = __dsub_rn(yd, (double)r0_v[c]);
+		}
+	};
+	row_tables(0);
+	const int yl = Y0 + nrows - 1;
+	const int keep0 = min(Y0, min(__builtin_amdgcn_readlane(r0_v[0], 0), __builtin_amdgcn_readlane(r0_v[1], 0)));
+	int lastneed = yl;
+#pragma unroll
+	for (int c = 0; c < 2; ++c) lastneed = max(lastneed, min((int)floor(map_dbl(yl, g.yc, H, g.s[c], g.ys[c])) + 1, H - 1));
+	const int lastneed_s = __builtin_amdgcn_readfirstlane(lastneed);
+	const uint32_t dst_bytes = (uint32_t)nrows * pitch;
+	const rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + (size_t)keep0 * pitch, 0,
+	                                                        (uint32_t)(lastneed_s - keep0 + 1) * pitch, 0x00020000);
+	const rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)Y0 * pitch, 0, dst_bytes, 0x00020000);
+	(void)rs_src;
+#pragma unroll
+	for (int i = 0; i < 2; ++i) stoff[i] = (stoff[i] == 0xFFFFFFFFu) ? dst_bytes : stoff[i];
+	const int tail_u = (nunits - 1) >> 6, tail_lane = (nunits - 1) & 63;
+
+	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
+	(void)vo_ld;
+	int ld = keep0 - 1;
+	uint32_t so_ld = 0;
+	auto issue = [&]() {
+		++ld;
+#if defined(__HIP_DEVICE_COMPILE__)
+		const int slot = lin_slot(ld, K, kmagic);
+		__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(ring + slot * WINB);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void *)row, 16, vo_ld, so_ld, 0, 0);
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void *)row, 16, vo_ld, so_ld, 1024, 0);
+#endif
+		so_ld += pitch;
+	};
+	auto fetch = [&](int keep, int need) {
+		const int target = min(min(need + mp.depth, keep + K - 1), lastneed_s);
+		while (ld < target) issue();
+		const int younger = ld - need;
+		if (younger >= 12) lin_wait_vm<12 * NU>();
+		else if (younger >= 10) lin_wait_vm<10 * NU>();
+		else if (younger >= 8) lin_wait_vm<8 * NU>();
+		else if (younger >= 6) lin_wait_vm<6 * NU>();
+		else if (younger >= 4) lin_wait_vm<4 * NU>();
+		else if (younger >= 3) lin_wait_vm<3 * NU>();
+		else if (younger >= 2) lin_wait_vm<2 * NU>();
+		else if (younger >= 1) lin_wait_vm<NU>();
+		else lin_wait_vm<0>();
+	};
+
+	uint32_t so_st = 0;
+	for (int r = 0; r < nrows; ++r) {
+		if (r && (r & 63) == 0) row_tables(r);
+		const int y = Y0 + r;
+		int r0[2], r1[2];
+		double fy[2], omfy[2];
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			r0[c] = __builtin_amdgcn_readlane(r0_v[c], r & 63);
+			r1[c] = (r0[c] == H - 1) ? r0[c] : r0[c] + 1;                    /* fix-ca.c:1149-1158 */
+			fy[c] = lin_readlane_f64(fy_v[c], r & 63);
+			omfy[c] = __dsub_rn(1.0, fy[c]);
+		}
+		/* the previous row's LDS reads (ring and staging) have returned: its stores consumed them */
+		fetch(min(y, min(r0[0], r0[1])), max(y, max(r1[0], r1[1])));
+		const uint32_t bI = (uint32_t)lin_slot(y, K, kmagic) * WINB;
+		uint32_t b0[2], b1[2];
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			b0[c] = (uint32_t)lin_slot(r0[c], K, kmagic) * WINB;
+			b1[c] = (uint32_t)lin_slot(r1[c], K, kmagic) * WINB;
+		}
+		S mine[PXL][3];                                                    /* my pixels: R, G, B */
+#pragma unroll
+		for (int j = 0; j < PXL; ++j) {
+			mine[j][1] = *reinterpret_cast<const S *>(ring + bI + goff[j]);    /* green is copied (fix-ca.c:1098) */
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				const double p00 = C::get(*reinterpret_cast<const S *>(ring + b0[c] + off0[j][c]));
+				const double p10 = C::get(*reinterpret_cast<const S *>(ring + b0[c] + off1[j][c]));
+				const double p01 = C::get(*reinterpret_cast<const S *>(ring + b1[c] + off0[j][c]));
+				const double p11 = C::get(*reinterpret_cast<const S *>(ring + b1[c] + off1[j][c]));
+				/* bilinear(), fix-ca.c:891-893, operation for operation */
+				const double a = __dadd_rn(p00, __dmul_rn(fx[j][c], __dsub_rn(p10, p00)));
+				const double b = __dadd_rn(p01, __dmul_rn(fx[j][c], __dsub_rn(p11, p01)));
+				mine[j][2 * c] = C::put(clip01(__dadd_rn(__dmul_rn(omfy[c], a), __dmul_rn(fy[c], b))));
+			}
+		}
+		/* my 24 bytes into the staging row, as dwords (written and read with one type: the compiler orders accesses by type) */
+		uint32_t w[LW];
+#pragma unroll
+		for (int j = 0; j < PXL; ++j)
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				if constexpr (SB == 4) w[3 * j + k] = __builtin_bit_cast(uint32_t, mine[j][k]);
+				else { const unsigned long long q = __builtin_bit_cast(unsigned long long, mine[j][k]); w[2 * k] = (uint32_t)q; w[2 * k + 1] = (uint32_t)(q >> 32); }
+			}
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int d = 0; d < LW; ++d) stage[LW * lane + d] = w[d];
+		asm volatile("" ::: "memory");                  /* one wave: its LDS operations complete in order, the reads below see these writes */
+		u32x4 out[2];
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int U = min(lane + 64 * i, LIN_RGB_ROW_BYTES / 16 - 1);
+#pragma unroll
+			for (int d = 0; d < 4; ++d) out[i][d] = stage[4 * U + d];
+		}
+		asm volatile("" ::: "memory");
+		/* scalar offset the constant 0: the store-data hazard of DESIGN.md §4 (tests/test_host_logic.py scans for it) */
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] == dst_bytes ? dst_bytes : stoff[i] + so_st, 0, 2);
+		if (tail_dw) {                                  /* the row's last unit is partial (widths that are not a multiple of 4 / 2 pixels) */
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				if (i == tail_u) {
+					const bool mine_t = lane == tail_lane;
+					const uint32_t o = (uint32_t)(X0 * PB + 16 * (lane + 64 * i)) + so_st;
+#pragma unroll
+					for (int d = 0; d < 3; ++d)
+						if (d < tail_dw) __builtin_amdgcn_raw_buffer_store_b32(out[i][d], rs_dst, mine_t ? o + 4 * d : dst_bytes, 0, 2);
+				}
+		}
+		so_st += pitch;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the next row's DMA and staging writes may overwrite what was read here */
+	}
+}
+
+template <typename S>
 const void *lin_kernel_nu(int nu)
 {
 	switch (nu) {
-	case 1:  return reinterpret_cast<const void *>(&k_lin<S, NCH, 1>);
-	case 2:  return reinterpret_cast<const void *>(&k_lin<S, NCH, 2>);
-	default: return reinterpret_cast<const void *>(&k_lin<S, NCH, 4>);
+	case 1:  return reinterpret_cast<const void *>(&k_lin<S, 1>);
+	case 2:  return reinterpret_cast<const void *>(&k_lin<S, 2>);
+	default: return reinterpret_cast<const void *>(&k_lin<S, 4>);
 	}
 }
 
 const void *lin_kernel_for(const FixcaGeom *g, int nu)
 {
-	if (g->nch == 4) {
-		switch (g->bpc) {
-		case 2:  return lin_kernel_nu<uint16_t, 4>(nu);
-		case 4:  return lin_kernel_nu<uint32_t, 4>(nu);
-		case -4: return lin_kernel_nu<float, 4>(nu);
-		case -8: return lin_kernel_nu<double, 4>(nu);
-		default: return nullptr;
-		}
-	}
 	if (g->nch == 3) {
+		if (nu != LIN_RGB_NU) return nullptr;
 		switch (g->bpc) {
-		case 4:  return lin_kernel_nu<uint32_t, 3>(nu);
-		case -4: return lin_kernel_nu<float, 3>(nu);
-		case -8: return lin_kernel_nu<double, 3>(nu);
+		case 4:  return reinterpret_cast<const void *>(&k_lin_rgb<uint32_t>);
+		case -4: return reinterpret_cast<const void *>(&k_lin_rgb<float>);
+		case -8: return reinterpret_cast<const void *>(&k_lin_rgb<double>);
 		default: return nullptr;
 		}
 	}
-	return nullptr;
+	switch (g->bpc) {
+	case 2:  return lin_kernel_nu<uint16_t>(nu);
+	case 4:  return lin_kernel_nu<uint32_t>(nu);
+	case -4: return lin_kernel_nu<float>(nu);
+	case -8: return lin_kernel_nu<double>(nu);
+	default: return nullptr;
+	}
 }
 
 }   /* namespace */
@@ -331,8 +503,9 @@ fixca_launch_lin_batch(const void *const *d_src, void *const *d_dst, int n_image
 	if (g->interp != 1 || (pl->nu != 1 && pl->nu != 2 && pl->nu != 4) || pl->depth < 1 || pl->depth > MOVE_DEPTH_MAX) return hipErrorInvalidValue;
 	const void *fn = lin_kernel_for(g, pl->nu);
 	if (!fn) return hipErrorInvalidValue;
-	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + 64;
-	if (lds > MOVE_LDS_MAX + 64) return hipErrorInvalidValue;
+	/* + a pad for RGBA (the 16-byte read of a last, partial unit), + the staging row for RGB */
+	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + (g->nch == 3 ? LIN_RGB_ROW_BYTES : 64);
+	if (lds > MOVE_LDS_MAX + LIN_RGB_ROW_BYTES) return hipErrorInvalidValue;
 	static std::mutex mu;
 	static const void *done[16];
 	static int ndone = 0;
@@ -341,7 +514,7 @@ fixca_launch_lin_batch(const void *const *d_src, void *const *d_dst, int n_image
 		bool seen = false;
 		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
 		if (!seen) {
-			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + 64);
+			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + LIN_RGB_ROW_BYTES);
 			if (ndone < 16) done[ndone++] = fn;
 		}
 	}

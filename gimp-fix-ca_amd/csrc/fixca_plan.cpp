@@ -678,12 +678,9 @@ static bool lin_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
 	if (g->interp != 1 || g->bpc == 1) return false;
-	/* RGB: a unit's samples change channel from lane to lane, so every sample pays per-row selects of its rows and
-	 * fractions, and the green ones are computed for nothing: on 4-byte samples that is slower than k_wcol (23-42 %
-	 * against 46 % of the HBM peak for RGB float, 28-38 against 46 for RGB u32); on doubles (two samples per unit) it
-	 * wins: 58.7 / 63.2 % (one image / six per launch) against 46.2 %, where k_wcol refuses RGB double LINEAR and the
-	 * one-thread-per-pixel kernel runs (profiles/r03_sweep_r3l.txt) */
-	if (g->nch == 3 && (g->bpc == 2 || (g->bpc != -8 && !fixca_debug_flag("FIXCA_LIN_RGB")))) return false;
+	/* RGB: 12- and 24-byte pixels through k_lin_rgb (a lane owns 24 bytes of whole pixels, the row is put together in
+	 * LDS); RGB u16 stays with k_wcol */
+	if (g->nch == 3 && g->bpc == 2) return false;
 	/* 16-bit samples: 4 samples per unit, 16 quotients and 70 operations per unit and row put the fp64 floor above the
 	 * memory time; k_wcol's rolling window does less arithmetic and stays (FIXCA_LIN_U16=1 to measure) */
 	if (g->bpc == 2 && !fixca_debug_flag("FIXCA_LIN_U16")) return false;
@@ -701,9 +698,10 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 *   many images per launch: 1-KiB rows x 32 rows, 8 in flight: float 69.9 %, u32 64.7 %, double 73.2 %. */
 	const bool integer = g->bpc > 0;
 	int nu = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	if (nu == 0) nu = (g->nch == 3) ? 2 : (batch || integer) ? 1 : 2;
+	if (nu == 0) nu = (batch || integer) ? 1 : 2;
 	if (nu == 3) nu = 2;
-	for (; nu >= 1; nu >>= 1) {
+	if (g->nch == 3) nu = 2;                             /* k_lin_rgb has one shape: 2-KiB ring rows, 1536-byte strips */
+	for (; nu >= (g->nch == 3 ? 2 : 1); nu >>= 1) {
 		const int winb = nu * 1024;
 		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
 		if (depth == 0) depth = batch ? 8 : (pb >= 24) ? 6 : 10;
@@ -715,7 +713,7 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		}
 		if (ring < span + 2 || (long long)ring * winb > MOVE_LDS_MAX) continue;
 		const int oc_env = env_int("FIXCA_OC", 0, 0, 1 << 20);
-		int oc_top = 64 * nu * 16 / pb / step * step;
+		int oc_top = (g->nch == 3 ? 1536 : 64 * nu * 16) / pb / step * step;
 		if (oc_env && oc_env < oc_top) oc_top = oc_env / step * step;
 		int oc_pick = 0;
 		for (int oc = oc_top; oc >= step && oc * pb >= winb / 2 && !oc_pick; oc -= step)
@@ -729,12 +727,12 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		pl->nstrips = (W + oc_pick - 1) / oc_pick;
 		int th;
 		if (batch) {
-			th = (g->nch == 3) ? 64 : 32;
+			th = 32;
 		} else {
 			/* the kernel has fp64 work to cover (40 operations per 4-byte pixel): one wave per SIMD, two for u32.  ONE
 			 * generation: a launch of 1029 waves on the 1024 slots a 32-KiB ring leaves (4 per CU) ran its last 5 waves
 			 * alone: 258 instead of 146 us for RGBA float */
-			const int want = integer ? 2048 : (g->nch == 3) ? 1536 : 1024;    /* RGB double: 1500 waves 58.7 %, 1050 waves 50.4 % */
+			const int want = integer ? 2048 : 1024;
 			int per_cu = (160 * 1024) / (ring * winb + 64);
 			if (per_cu > 16) per_cu = 16;
 			if (per_cu < 1) per_cu = 1;
@@ -851,7 +849,7 @@ static int make_plan_uncached(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
  * more than the kernel's own launch cost), and a caller such as the plug-in's preview or a
  * batch loop repeats the same geometry: the last plan is kept per thread.  The tuning
  * environment variables are part of the key so that a changed variable re-plans. */
-static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_NO_LIN", "FIXCA_NO_CUB", "FIXCA_CUB_ALL", "FIXCA_LIN_U16", "FIXCA_LIN_RGB", "FIXCA_MOVE_NU", "FIXCA_MOVE_DEPTH", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
+static const char *const plan_env[] = { "FIXCA_DEBUG", "FIXCA_NO_MOVE", "FIXCA_NO_LIN", "FIXCA_NO_CUB", "FIXCA_CUB_ALL", "FIXCA_LIN_U16", "FIXCA_MOVE_NU", "FIXCA_MOVE_DEPTH", "FIXCA_NO_WCOL", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS", "FIXCA_NO_ROLL", "FIXCA_NO_SCAN", "FIXCA_RING", "FIXCA_OC",
                                         "FIXCA_TH" };
 
 static void env_signature(char *buf, size_t n)

@@ -204,7 +204,7 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
         raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
-    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2 and (nch == 4 or bpc == -8))
+    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2)
             else "ring-cubic" if (interp == 2 and nch == 4 and bpc == -8) else "wide-roll")
     assert want in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
@@ -391,10 +391,9 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
     """k_lin (fixca_lin.hip): LINEAR on RGBA u32 / float / double (u16 on request) through the LDS ring, the reference's
     bilinear arithmetic in fp64 operation for operation: the oracle's bytes, for ring rows of 1, 2 and 4 KiB, short and
     tall tiles, row ranges, edge clamping (lens in a corner, shifts off the image), floats outside [0, 1] (clipped in
-    LINEAR, fix-ca.c:893; green and alpha copied unclipped), odd widths (RGB rows and u16 rows that end inside a unit)"""
+    LINEAR, fix-ca.c:893; green and alpha copied unclipped), odd widths (RGB rows and u16 rows that end inside a unit).
+    RGB runs k_lin_rgb (a lane owns 24 bytes of whole pixels, the output row is put together in LDS)"""
     torch = torch_cuda
-    if nch == 3 and bpc != -8:
-        monkeypatch.setenv("FIXCA_LIN_RGB", "1")            # RGB u32 / float: slower than k_wcol, planned only on request
     if nch == 3 and bpc == 2:
         pytest.skip("RGB u16 LINEAR stays with k_wcol")
     w, h = shape
