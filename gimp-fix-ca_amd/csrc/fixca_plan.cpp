@@ -704,7 +704,10 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	for (; nu >= (g->nch == 3 ? 2 : 1); nu >>= 1) {
 		const int winb = nu * 1024;
 		int depth = env_int("FIXCA_MOVE_DEPTH", 0, 0, MOVE_DEPTH_MAX);
-		if (depth == 0) depth = batch ? 8 : (pb >= 24) ? 6 : 10;
+		/* rows in flight (profiles/r03_sweep_r3s.txt): the formats with more arithmetic per byte trade prefetch for occupancy.
+		 * RGB (24 bytes and 4 or 2 computed samples per lane, a staging row in LDS): 3-4 rows (float, batched: 4 rows 65.6 %,
+		 * 8 rows 55.8, 12 rows 48.1); RGBA u32 4-6 rows (batched: 6 rows 67.0 %, 8 rows 63.0); RGBA float / double 8-10 / 6 */
+		if (depth == 0) depth = (g->nch == 3) ? (batch ? 4 : 3) : integer ? (batch ? 6 : 4) : batch ? 8 : (pb >= 24) ? 6 : 10;
 		if (depth < 2) depth = 2;
 		int ring = env_int("FIXCA_RING", 0, 0, 96);
 		if (ring == 0) {
@@ -728,6 +731,10 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		int th;
 		if (batch) {
 			th = 32;
+		} else if (g->nch == 3) {
+			/* RGB, one image per launch: many short tiles (float 100 rows x 47 strips = 1880 waves 57.9 %, 191 rows 53.4;
+			 * double 40 rows = 9400 waves 65.1 %, 364 rows 56.5): the kernel wants occupancy, not fat waves */
+			th = (pb == 12) ? 100 : 40;
 		} else {
 			/* the kernel has fp64 work to cover (40 operations per 4-byte pixel): one wave per SIMD, two for u32.  ONE
 			 * generation: a launch of 1029 waves on the 1024 slots a 32-KiB ring leaves (4 per CU) ran its last 5 waves
