@@ -104,7 +104,7 @@ FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, i
  *   6 roll            8-bit LDS-ring row-rolling kernel, RGBA8 and RGB8: the main kernel
  *   7 wide-roll-fp64  u16 / u32 / float / double, LINEAR and CUBIC, fp64 rolling window
  *   8 move-none       u16 / u32 / float / double, NONE: LDS-ring byte mover
- *   9 ring-linear-fp64 RGBA u32 / float / double and RGB double, LINEAR: LDS ring + fp64 bilinear
+ *   9 ring-linear-fp64 u32 / float / double, RGBA and RGB, LINEAR: LDS ring + fp64 bilinear
  *  10 ring-cubic-fp64  RGBA double (and float in batches), CUBIC: LDS ring + a rolling window per lane
  * (5 is retired.)  Usable with no GPU: nothing is launched.  For LINEAR / CUBIC on the wide
  * sample types the planner asks the HIP runtime for the current device's occupancy (this
