@@ -96,6 +96,30 @@ __device__ __forceinline__ S exact_cubic_sample(const S *__restrict__ src, const
 }
 
 
+/* one output sample of channel c (0 red, 1 blue) at (x, y) for LINEAR, operation for operation (fix-ca.c:1160-1185,
+ * bilinear :882-894): what the 16-bit LINEAR weight form (fixca_lin.hip) falls back to near a rounding boundary.  The
+ * form computes h = fma(fx, s1 - s0, s0) per row and x = fma(fy, h1 - h0, h0) on the integer samples; the reference's
+ * value differs from it by rounding errors only: 4 quotients s / 65535, 3 + 3 + 4 operations on values <= 2 and the final
+ * multiplication, each <= 2^-53 relative: |x_ref - x| < 15 * 2.2e-16 * 65535 = 2.2e-10 samples (measured over 24 million
+ * windows: 2.2e-11, tests/c/weightbound_linear.c), the form's own error < 4 * 2^-53 * 65535 = 3e-11: far inside
+ * WIDE_FAST_EPS. */
+template <typename S, int NCH>
+__device__ __forceinline__ S exact_linear_sample(const S *__restrict__ src, const FixcaGeom &g, int x, int y, int c)
+{
+	typedef Codec<S> C;
+	const size_t pitch = (size_t)g.W * NCH;
+	const double yd = map_dbl(y, g.yc, g.H, g.s[c], g.ys[c]), xd = map_dbl(x, g.xc, g.W, g.s[c], g.xs[c]);
+	const int r0 = (int)floor(yd), c0 = (int)floor(xd);
+	const double fy = __dsub_rn(yd, (double)r0), fx = __dsub_rn(xd, (double)c0);
+	const int r1 = (r0 == g.H - 1) ? r0 : r0 + 1, c1 = (c0 == g.W - 1) ? c0 : c0 + 1;
+	const S *row0 = src + (size_t)r0 * pitch + 2 * c, *row1 = src + (size_t)r1 * pitch + 2 * c;
+	const double p00 = C::get(row0[(size_t)c0 * NCH]), p10 = C::get(row0[(size_t)c1 * NCH]);
+	const double p01 = C::get(row1[(size_t)c0 * NCH]), p11 = C::get(row1[(size_t)c1 * NCH]);
+	const double a = __dadd_rn(p00, __dmul_rn(fx, __dsub_rn(p10, p00)));
+	const double b = __dadd_rn(p01, __dmul_rn(fx, __dsub_rn(p11, p01)));
+	return C::put(clip01(__dadd_rn(__dmul_rn(__dsub_rn(1.0, fy), a), __dmul_rn(fy, b))));
+}
+
 }   /* namespace fixca_codec */
 
 #endif

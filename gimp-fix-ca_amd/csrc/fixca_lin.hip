@@ -57,12 +57,18 @@ __device__ __forceinline__ double lin_readlane_f64(double v, int l)
 	return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
-template <typename S, int NU>          /* S: sample type; NU: KiB per ring row = units per lane and row */
+/* FAST (16-bit samples only): the weight form: both interpolations as fused multiply-adds on the integer samples, the
+ * result rounded as the reference rounds, and every sample whose fraction is within WIDE_FAST_EPS of a rounding boundary
+ * recomputed operation for operation from the source image (exact_linear_sample; bound in fixca_codec.h).  Without it
+ * a 16-bit unit costs 16 exact quotients and 70 operations and the kernel is bound by fp64 issue (33-40 % of the HBM
+ * peak against k_wcol's 55 %); with it 4 conversions and 5 operations per sample. */
+template <typename S, int NU, bool FAST = false>   /* S: sample type; NU: KiB per ring row = units per lane and row */
 __global__ __launch_bounds__(64) void
 k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
 	typedef Codec<S> C;
+	static_assert(!FAST || sizeof(S) == 2, "the weight form is for 16-bit samples");
 	constexpr int SB = (int)sizeof(S);
 	constexpr int PB = 4 * SB;                         /* RGBA                                          */
 	constexpr int WINB = NU * 1024;
@@ -98,6 +104,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	double   fx[NU][NC];
 	uint32_t idoff[NU], stoff[NU];
 	int      blue[NU];                                 /* double: this unit holds (B, A), not (R, G)                      */
+	int      pxcol[FAST ? NU : 1][FAST ? NC : 1];      /* FAST: the output column of the sample (for the recomputation)   */
 #pragma unroll
 	for (int i = 0; i < NU; ++i) {
 		const int U = min(lane + 64 * i, nunits - 1);
@@ -107,6 +114,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		for (int j = 0; j < NC; ++j) {
 			const int c = (SB == 8) ? blue[i] : (j & 1);                     /* 0 red, 1 blue */
 			const int px = min(X0 + ((SB == 8) ? U / 2 : (SB == 4) ? U : 2 * U + j / 2), W - 1);
+			if constexpr (FAST) pxcol[i][j] = px;
 			const double xd = map_dbl(px, g.xc, W, g.s[c], g.xs[c]);
 			const int c0 = (int)floor(xd);
 			const int c1 = (c0 == W - 1) ? c0 : c0 + 1;                      /* fix-ca.c:1170-1177 */
@@ -208,6 +216,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		for (int i = 0; i < NU; ++i) {
 			u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
 			S res[NC];
+			uint32_t redo = 0;
 #pragma unroll
 			for (int j = 0; j < NC; ++j) {
 				uint32_t a0, a1;
@@ -219,14 +228,38 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 					a0 = b0[j & 1]; a1 = b1[j & 1];
 					wy = fy[j & 1]; wy1 = omfy[j & 1];
 				}
-				const double p00 = C::get(*reinterpret_cast<const S *>(ring + a0 + off0[i][j]));
-				const double p10 = C::get(*reinterpret_cast<const S *>(ring + a0 + off1[i][j]));
-				const double p01 = C::get(*reinterpret_cast<const S *>(ring + a1 + off0[i][j]));
-				const double p11 = C::get(*reinterpret_cast<const S *>(ring + a1 + off1[i][j]));
-				/* bilinear(), fix-ca.c:891-893, operation for operation */
-				const double a = __dadd_rn(p00, __dmul_rn(fx[i][j], __dsub_rn(p10, p00)));
-				const double b = __dadd_rn(p01, __dmul_rn(fx[i][j], __dsub_rn(p11, p01)));
-				res[j] = C::put(clip01(__dadd_rn(__dmul_rn(wy1, a), __dmul_rn(wy, b))));
+				const S s00 = *reinterpret_cast<const S *>(ring + a0 + off0[i][j]), s10 = *reinterpret_cast<const S *>(ring + a0 + off1[i][j]);
+				const S s01 = *reinterpret_cast<const S *>(ring + a1 + off0[i][j]), s11 = *reinterpret_cast<const S *>(ring + a1 + off1[i][j]);
+				if constexpr (FAST) {
+					const double h0 = fma(fx[i][j], (double)s10 - (double)s00, (double)s00);
+					const double h1 = fma(fx[i][j], (double)s11 - (double)s01, (double)s01);
+					double xv = fma(wy, h1 - h0, h0);
+					xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
+					const double fr = __builtin_amdgcn_fract(xv);
+					res[j] = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
+					redo |= (__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS ? 1u : 0u) << j;
+				} else {
+					const double p00 = C::get(s00), p10 = C::get(s10), p01 = C::get(s01), p11 = C::get(s11);
+					/* bilinear(), fix-ca.c:891-893, operation for operation */
+					const double a = __dadd_rn(p00, __dmul_rn(fx[i][j], __dsub_rn(p10, p00)));
+					const double b = __dadd_rn(p01, __dmul_rn(fx[i][j], __dsub_rn(p11, p01)));
+					res[j] = C::put(clip01(__dadd_rn(__dmul_rn(wy1, a), __dmul_rn(wy, b))));
+				}
+			}
+			if constexpr (FAST) {
+				if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0) != 0, 0)) {
+					/* a few samples per image: recomputed the reference's way from the source image */
+					while (redo) {
+						const int q = __builtin_ctz(redo);
+						redo &= redo - 1;
+						int col = pxcol[i][0];
+#pragma unroll
+						for (int j = 1; j < NC; ++j) col = (q == j) ? pxcol[i][j] : col;
+						const S e = fixca_codec::exact_linear_sample<S, 4>(reinterpret_cast<const S *>(src), g, col, y, q & 1);
+#pragma unroll
+						for (int j = 0; j < NC; ++j) res[j] = (q == j) ? e : res[j];
+					}
+				}
 			}
 			if constexpr (SB == 2) {
 				v.x = (v.x & 0xFFFF0000u) | (uint32_t)res[0]; v.y = (v.y & 0xFFFF0000u) | (uint32_t)res[1];
@@ -473,7 +506,7 @@ const void *lin_kernel_nu(int nu)
 	}
 }
 
-const void *lin_kernel_for(const FixcaGeom *g, int nu)
+const void *lin_kernel_for(const FixcaGeom *g, int nu, bool fast)
 {
 	if (g->nch == 3) {
 		if (nu != LIN_RGB_NU) return nullptr;
@@ -485,7 +518,13 @@ const void *lin_kernel_for(const FixcaGeom *g, int nu)
 		}
 	}
 	switch (g->bpc) {
-	case 2:  return lin_kernel_nu<uint16_t>(nu);
+	case 2:
+		if (!fast) return lin_kernel_nu<uint16_t>(nu);
+		switch (nu) {
+		case 1:  return reinterpret_cast<const void *>(&k_lin<uint16_t, 1, true>);
+		case 2:  return reinterpret_cast<const void *>(&k_lin<uint16_t, 2, true>);
+		default: return reinterpret_cast<const void *>(&k_lin<uint16_t, 4, true>);
+		}
 	case 4:  return lin_kernel_nu<uint32_t>(nu);
 	case -4: return lin_kernel_nu<float>(nu);
 	case -8: return lin_kernel_nu<double>(nu);
@@ -501,13 +540,13 @@ fixca_launch_lin_batch(const void *const *d_src, void *const *d_dst, int n_image
 	if (g->y2 <= g->y1) return hipSuccess;
 	if (n_images < 1 || n_images > MOVE_BATCH_MAX) return hipErrorInvalidValue;
 	if (g->interp != 1 || (pl->nu != 1 && pl->nu != 2 && pl->nu != 4) || pl->depth < 1 || pl->depth > MOVE_DEPTH_MAX) return hipErrorInvalidValue;
-	const void *fn = lin_kernel_for(g, pl->nu);
+	const void *fn = lin_kernel_for(g, pl->nu, pl->wide_fast != 0);
 	if (!fn) return hipErrorInvalidValue;
 	/* + a pad for RGBA (the 16-byte read of a last, partial unit), + the staging row for RGB */
 	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + (g->nch == 3 ? LIN_RGB_ROW_BYTES : 64);
 	if (lds > MOVE_LDS_MAX + LIN_RGB_ROW_BYTES) return hipErrorInvalidValue;
 	static std::mutex mu;
-	static const void *done[16];
+	static const void *done[24];
 	static int ndone = 0;
 	{
 		std::lock_guard<std::mutex> lock(mu);
@@ -515,7 +554,7 @@ fixca_launch_lin_batch(const void *const *d_src, void *const *d_dst, int n_image
 		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
 		if (!seen) {
 			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + LIN_RGB_ROW_BYTES);
-			if (ndone < 16) done[ndone++] = fn;
+			if (ndone < 24) done[ndone++] = fn;
 		}
 	}
 	MovePlan mp;

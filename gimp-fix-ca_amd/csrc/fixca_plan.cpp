@@ -466,7 +466,7 @@ static void finish_plan(const FixcaGeom *g, FixcaPlan *pl)
  * Scales other than 1 spread the fractions over the columns and rows and such samples are a few per image. */
 static bool wide_fast_ok(const FixcaGeom *g)
 {
-	if (g->bpc != 2 || g->interp != 2 || fixca_debug_flag("FIXCA_WCOL_REF")) return false;
+	if (g->bpc != 2 || g->interp == 0 || fixca_debug_flag("FIXCA_WCOL_REF")) return false;       /* 16-bit samples; CUBIC in k_wcol, LINEAR in k_lin */
 	if (fixca_debug_flag("FIXCA_WCOL_WEIGHTS")) return true;          /* tests: the recomputation path under load */
 	const int rows = g->y2 - g->y1;
 	for (int c = 0; c < 2; ++c) {
@@ -517,7 +517,7 @@ static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 		}
 	pl->kernel = FIXCA_K_WCOL;
 	pl->oc = oc;
-	pl->wide_fast = wide_fast_ok(g) ? 1 : 0;
+	pl->wide_fast = (g->interp == 2 && wide_fast_ok(g)) ? 1 : 0;      /* k_wcol has the weight form for CUBIC only */
 	/* Tile height: all tiles resident at once, the same number on every SIMD.  The kernel is bound by fp64 issue and its
 	 * waves all do the same work, so a launch lasts as long as its fullest SIMD (6000x4000 RGBA u16, 3 resident waves
 	 * per SIMD: th 66 -> 3050 waves 132 us; th 60 -> 3350 waves 164 us; th 90 -> 2250 waves 170 us).  Several rounds
@@ -681,9 +681,11 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	/* RGB: 12- and 24-byte pixels through k_lin_rgb (a lane owns 24 bytes of whole pixels, the row is put together in
 	 * LDS); RGB u16 stays with k_wcol */
 	if (g->nch == 3 && g->bpc == 2) return false;
-	/* 16-bit samples: 4 samples per unit, 16 quotients and 70 operations per unit and row put the fp64 floor above the
-	 * memory time; k_wcol's rolling window does less arithmetic and stays (FIXCA_LIN_U16=1 to measure) */
-	if (g->bpc == 2 && !fixca_debug_flag("FIXCA_LIN_U16")) return false;
+	/* 16-bit samples: in the reference's operation order 4 samples per unit, 16 quotients and 70 operations per unit
+	 * and row put the fp64 floor above the memory time (33-40 % against k_wcol's 55 %; FIXCA_LIN_U16=1 to measure): only
+	 * in the weight form, where the planner allows it (not on shifts by halves, where rounding boundaries are common) */
+	const bool fast = g->bpc == 2 && wide_fast_ok(g);
+	if (g->bpc == 2 && !fast && !fixca_debug_flag("FIXCA_LIN_U16")) return false;
 	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
 	const long long pitch = (long long)W * pb;
 	if (pitch % 4) return false;
@@ -723,6 +725,7 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			if (lin_cols_fit(g, oc, winb)) oc_pick = oc;
 		if (!oc_pick) continue;
 		pl->kernel = FIXCA_K_LIN;
+		pl->wide_fast = fast ? 1 : 0;
 		pl->nu = nu;
 		pl->depth = depth;
 		pl->oc = oc_pick;
@@ -966,7 +969,7 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 	else if (pl->kernel == FIXCA_K_MOVE || pl->kernel == FIXCA_K_LIN || pl->kernel == FIXCA_K_CUB)
 		snprintf(buf, n, "%s %s bpp=%d bpc=%d oc=%d th=%d ring=%dx%dK depth=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel], in[g->interp], g->bpp, g->bpc,
 		         pl->oc, pl->th, pl->ring, pl->nu, pl->depth, pl->nstrips, pl->nchunks, pl->nwaves,
-		         "");
+		         (pl->kernel == FIXCA_K_LIN && pl->wide_fast) ? " weights+recheck" : "");
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_ROLL)
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);

@@ -188,7 +188,7 @@ def _fuzz_cases(n, seed):
     return cases
 
 
-@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (4, 4, 2), (2, 3, 2), (2, 3, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0),
+@pytest.mark.parametrize("bpc,nch,interp", [(-8, 4, 2), (-8, 3, 2), (2, 4, 2), (4, 4, 2), (2, 3, 2), (2, 3, 1), (2, 4, 1), (-4, 4, 2), (4, 4, 1), (2, 4, 0), (2, 3, 0),
                                             (4, 4, 0), (-4, 3, 0), (-8, 4, 0), (-8, 3, 0)], ids=str)
 def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
     """k_wcol against the one-thread-per-pixel kernel (itself checked against the oracle above) on BASELINE's
@@ -204,7 +204,7 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
         raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
-    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2)
+    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and (bpc != 2 or nch == 4))
             else "ring-cubic" if (interp == 2 and nch == 4 and bpc == -8) else "wide-roll")
     assert want in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
@@ -321,8 +321,8 @@ def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
                        (2, dict(lens_x=w // 2, lens_y=h // 2, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0))):
         p = fixca.make_params(interpolation=interp, **kw)
         kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
-        if interp == 1 and bpc != 2:
-            assert kid in (1, 7, 9), desc                   # the LDS-ring LINEAR kernel where its window fits
+        if interp == 1 and (bpc != 2 or nch == 4):
+            assert kid in (1, 7, 9), desc                   # the LDS-ring LINEAR kernel where its window fits (16-bit: and the weight form is allowed)
         elif nch == 4:
             assert kid in (7, 10), desc                     # ... and the LDS-ring CUBIC kernel on RGBA
         else:
@@ -400,17 +400,29 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
     sb = abs(bpc)
     img = _wide_image(dtype, w, h, nch, 5100 + abs(bpc) + w + nch)
     src = torch.from_numpy(img.view(np.uint8).reshape(h, w, nch * sb)).cuda()
-    monkeypatch.setenv("FIXCA_LIN_U16", "1")
     took = 0
-    for pi, kw in enumerate(MOVE_PARAMS):
+    cases = MOVE_PARAMS + ([dict(lens_x=0.5, lens_y=0.5, x_blue=0.5, y_red=-0.5)] if bpc == 2 else [])
+    for pi, kw in enumerate(cases):
         p = fixca.make_params(interpolation=1, **_scaled(kw, w, h))
         ref = pyoracle.region(img, pyoracle.make_params(**p.as_dict()), bpc=bpc).view(np.uint8).reshape(h, w, nch * sb)
+        # 16-bit samples: the weight form with exact recomputation where the planner allows it (cases 0, 3), forced on
+        # half-pixel shifts where rounding boundaries are everywhere (case 4), and the reference's operation order in the
+        # same kernel (FIXCA_LIN_U16 with FIXCA_WCOL_REF) for the rest
+        for name in ("FIXCA_LIN_U16", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS"):
+            monkeypatch.delenv(name, raising=False)
+        if bpc == 2 and pi == 4:
+            monkeypatch.setenv("FIXCA_WCOL_WEIGHTS", "1")
+        elif bpc == 2 and pi in (1, 2):
+            monkeypatch.setenv("FIXCA_LIN_U16", "1")
+            monkeypatch.setenv("FIXCA_WCOL_REF", "1")
         for nu, th in ((0, 0), (1, 7), (2, 64), (4, 200)):
             monkeypatch.setenv("FIXCA_MOVE_NU", str(nu))
             monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
             kid, desc = fixca.plan(w, h, nch * sb, bpc, p)
-            if pi in (0, 2, 3):
+            if pi in (0, 2, 3, 4):
                 assert kid == 9, desc
+            if bpc == 2 and kid == 9:
+                assert ("weights+recheck" in desc) == (pi in (0, 3, 4)), desc
             took += kid == 9
             dst = torch.full_like(src, 0x3C)
             fixca.fix_ca_region(src, dst, w, h, nch * sb, bpc, p, 0, w, 0, h, True)
@@ -422,6 +434,8 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
             assert got[9:h - 4].tobytes() == ref[9:h - 4].tobytes(), (desc, kw)
             assert np.all(got[:9] == 0x5A) and np.all(got[h - 4:] == 0x5A)
     assert took >= 12
+    for name in ("FIXCA_LIN_U16", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS"):
+        monkeypatch.delenv(name, raising=False)
     # a batch of images in one launch
     if bpc == -4 and nch == 4:
         p = fixca.make_params(interpolation=1, **_scaled(MOVE_PARAMS[0], w, h))

@@ -101,3 +101,16 @@ def test_weight_form_error_bound(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     worst, unflagged, flagged = out.stdout.split()
     assert out.returncode == 0 and float(worst) < 1e-8 and int(unflagged) == 0 and int(flagged) > 0, out.stdout
+
+
+def test_weight_form_error_bound_linear(tmp_path):
+    """the 16-bit LINEAR weight form (k_lin<u16, .., FAST>, fixca_lin.hip): over 24 million 2 x 2 windows the form
+    fma(fy, h1 - h0, h0), h = fma(fx, s1 - s0, s0) stays within 1e-9 samples of the reference's operation order
+    (analytic bound 2.2e-10, recheck band 1e-6), and no unflagged sample rounds differently"""
+    import subprocess
+    exe = tmp_path / "weightbound_linear"
+    src = os.path.join(os.path.dirname(__file__), "c", "weightbound_linear.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    worst, unflagged, flagged = out.stdout.split()
+    assert out.returncode == 0 and float(worst) < 1e-9 and int(unflagged) == 0 and int(flagged) > 0, out.stdout

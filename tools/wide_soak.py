@@ -1,4 +1,4 @@
-"""GPU box: soak of k_wcol's 16-bit weight forms (CUBIC, or LINEAR with SOAK_INTERP=1) against the one-thread-per-pixel fp64 kernel: N random parameter
+"""GPU box: soak of the 16-bit weight forms (k_wcol_weights: CUBIC; k_lin<u16, FAST>: LINEAR with SOAK_INTERP=1) against the one-thread-per-pixel fp64 kernel: N random parameter
 sets (lateral amounts up to the plug-in's +-30, lens anywhere, some with directional shifts) on 6000x4000 RGBA / RGB u16
 images of four kinds (noise, smooth ramps, ramps with a little noise, random 0 / 65535 steps).  Every sample must be identical.
 usage: wide_soak.py [N]"""
