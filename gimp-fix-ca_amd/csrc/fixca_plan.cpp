@@ -685,7 +685,9 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 * and row put the fp64 floor above the memory time (33-40 % against k_wcol's 55 %; FIXCA_LIN_U16=1 to measure): only
 	 * in the weight form, where the planner allows it (not on shifts by halves, where rounding boundaries are common) */
 	const bool fast = g->bpc == 2 && wide_fast_ok(g);
-	if (g->bpc == 2 && !fast && !fixca_debug_flag("FIXCA_LIN_U16")) return false;
+	/* ... and in a batch: 59.8 against 53.0 % for k_wcol six images per launch; one image per launch the best shape
+	 * only draws (56.4 against 56.7 %), so k_wcol keeps the single call (profiles/r03_sweep_r3u.txt) */
+	if (g->bpc == 2 && !((fast && (flags & FIXCA_PLAN_BATCH)) || fixca_debug_flag("FIXCA_LIN_U16"))) return false;
 	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
 	const long long pitch = (long long)W * pb;
 	if (pitch % 4) return false;
@@ -700,7 +702,7 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 *   many images per launch: 1-KiB rows x 32 rows, 8 in flight: float 69.9 %, u32 64.7 %, double 73.2 %. */
 	const bool integer = g->bpc > 0;
 	int nu = env_int("FIXCA_MOVE_NU", 0, 0, MOVE_NU_MAX);
-	if (nu == 0) nu = (batch || integer) ? 1 : 2;
+	if (nu == 0) nu = (g->bpc == 2) ? 2 : (batch || integer) ? 1 : 2;
 	if (nu == 3) nu = 2;
 	if (g->nch == 3) nu = 2;                             /* k_lin_rgb has one shape: 2-KiB ring rows, 1536-byte strips */
 	for (; nu >= (g->nch == 3 ? 2 : 1); nu >>= 1) {
@@ -709,7 +711,7 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		/* rows in flight (profiles/r03_sweep_r3s.txt): the formats with more arithmetic per byte trade prefetch for occupancy.
 		 * RGB (24 bytes and 4 or 2 computed samples per lane, a staging row in LDS): 3-4 rows (float, batched: 4 rows 65.6 %,
 		 * 8 rows 55.8, 12 rows 48.1); RGBA u32 4-6 rows (batched: 6 rows 67.0 %, 8 rows 63.0); RGBA float / double 8-10 / 6 */
-		if (depth == 0) depth = (g->nch == 3) ? (batch ? 4 : 3) : integer ? (batch ? 6 : 4) : batch ? 8 : (pb >= 24) ? 6 : 10;
+		if (depth == 0) depth = (g->nch == 3) ? (batch ? 4 : 3) : (g->bpc == 2) ? 3 : integer ? (batch ? 6 : 4) : batch ? 8 : (pb >= 24) ? 6 : 10;
 		if (depth < 2) depth = 2;
 		int ring = env_int("FIXCA_RING", 0, 0, 96);
 		if (ring == 0) {

@@ -204,7 +204,7 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
         raw = raw.view(torch.int32).to(torch.float32).abs_().mul_(1.0 / 2147483648.0).view(torch.uint8).reshape(h, w, nch * sb)
     if bpc == -8:
         raw = raw.view(torch.int64).to(torch.float64).abs_().mul_(1.0 / 9223372036854775808.0).view(torch.uint8).reshape(h, w, nch * sb)
-    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and (bpc != 2 or nch == 4))
+    want = ("move-none" if interp == 0 else "ring-linear" if (interp == 1 and bpc != 2)
             else "ring-cubic" if (interp == 2 and nch == 4 and bpc == -8) else "wide-roll")
     assert want in fixca.plan(w, h, nch * sb, bpc, p)[1]
     a, b = torch.zeros_like(raw), torch.zeros_like(raw)
@@ -410,10 +410,11 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
         # same kernel (FIXCA_LIN_U16 with FIXCA_WCOL_REF) for the rest
         for name in ("FIXCA_LIN_U16", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS"):
             monkeypatch.delenv(name, raising=False)
+        if bpc == 2:
+            monkeypatch.setenv("FIXCA_LIN_U16", "1")             # single calls: the planner sends 16-bit samples here in batches only
         if bpc == 2 and pi == 4:
             monkeypatch.setenv("FIXCA_WCOL_WEIGHTS", "1")
         elif bpc == 2 and pi in (1, 2):
-            monkeypatch.setenv("FIXCA_LIN_U16", "1")
             monkeypatch.setenv("FIXCA_WCOL_REF", "1")
         for nu, th in ((0, 0), (1, 7), (2, 64), (4, 200)):
             monkeypatch.setenv("FIXCA_MOVE_NU", str(nu))
@@ -436,8 +437,8 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
     assert took >= 12
     for name in ("FIXCA_LIN_U16", "FIXCA_WCOL_REF", "FIXCA_WCOL_WEIGHTS"):
         monkeypatch.delenv(name, raising=False)
-    # a batch of images in one launch
-    if bpc == -4 and nch == 4:
+    # a batch of images in one launch (16-bit samples take this kernel by themselves there)
+    if bpc in (-4, 2) and nch == 4:
         p = fixca.make_params(interpolation=1, **_scaled(MOVE_PARAMS[0], w, h))
         imgs = [_wide_image(dtype, w, h, nch, 5200 + k) for k in range(5)]
         srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]

@@ -194,10 +194,11 @@ def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
             if kid != 10:
                 desc = descb
         elif interp == 1 and bpc == 2 and nch == 4:
-            assert kid in (7, 9) and kidb == kid, desc           # 16-bit RGBA: the ring kernel's weight form, except on shifts by halves
-            if kid == 7:
+            assert kid == 7 and kidb in (7, 9), desc             # 16-bit RGBA: the ring kernel's weight form in batches, except on shifts by halves
+            if kidb == 7:
                 continue
-            assert "weights+recheck" in desc
+            assert "weights+recheck" in descb
+            desc = descb
         elif interp == 1 and bpc != 2:
             assert kid == 9 and kidb == 9, desc
         else:
