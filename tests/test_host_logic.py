@@ -214,8 +214,8 @@ def test_ring_kernel_plans_of_the_wide_types(bpc, nch, interp):
             assert f["ring"] >= f["depth"] + 2
         f = _plan_fields(desc)
         slots = min(16, (160 * 1024) // (f["ring"] * f["nu"] * 1024 + 64)) * 256
-        if interp == 0 or (interp == 1 and nch == 4):
-            assert f["waves"] <= slots, desc                         # the movers and RGBA LINEAR: one generation of fat waves
+        if interp == 0 or (interp == 1 and nch == 4 and bpc != 2):
+            assert f["waves"] <= slots, desc                         # the movers and RGBA LINEAR, one image per launch: one generation of fat waves
         # (RGB LINEAR and CUBIC are bound by their arithmetic: many short tiles, several generations)
         assert _plan_fields(descb)["th"] in (32, 64)                 # many images per launch: short tiles
 
