@@ -297,16 +297,16 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #define LIN_RGB_ROW_BYTES  (64 * LIN_RGB_LANE_BYTES)   /* 1536: the strip's output row, assembled in LDS */
 #define LIN_RGB_NU         2                        /* 2-KiB ring rows: 170 columns of RGB float, 85 of RGB double */
 
-template <typename S, bool FAST = false>           /* u32, float, double; u16 in the weight form (FAST, see k_lin) */
+template <typename S>                              /* u32, float, double */
 __global__ __launch_bounds__(64) void
 k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t ring[];     /* K ring rows, then the staging row */
 	typedef Codec<S> C;
 	constexpr int SB = (int)sizeof(S);
-	static_assert(FAST == (SB == 2), "16-bit samples in the weight form only; the reference's order stays with k_wcol");
+	static_assert(SB == 4 || SB == 8, "RGB u16 stays with k_wcol");
 	constexpr int PB = 3 * SB;
-	constexpr int PXL = LIN_RGB_LANE_BYTES / PB;       /* pixels per lane: 4, 2 or 1                    */
+	constexpr int PXL = LIN_RGB_LANE_BYTES / PB;       /* pixels per lane: 2 or 1                       */
 	constexpr int NU = LIN_RGB_NU;
 	constexpr int WINB = NU * 1024;
 	constexpr int LW = LIN_RGB_LANE_BYTES / 4;         /* dwords a lane contributes to the row          */
@@ -330,7 +330,7 @@ k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	int lo = X0;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lo = min(lo, (int)floor(map_dbl(X0, g.xc, W, g.s[c], g.xs[c])));
-	constexpr int CA = (PB % 8 == 0) ? 2 : (PB % 4 == 0) ? 4 : 8;   /* columns per 16 bytes of row: the DMA's global address stays 16-byte aligned in the row */
+	constexpr int CA = (PB % 8 == 0) ? 2 : 4;          /* columns per 16 bytes of row: the DMA's global address stays 16-byte aligned in the row */
 	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(CA - 1));
 
 	/* ---- per-lane constants: my pixels, the taps of their red and blue samples ---------------------------------------- */
@@ -445,28 +445,14 @@ k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 			mine[j][1] = *reinterpret_cast<const S *>(ring + bI + goff[j]);    /* green is copied (fix-ca.c:1098) */
 #pragma unroll
 			for (int c = 0; c < 2; ++c) {
-				const S s00 = *reinterpret_cast<const S *>(ring + b0[c] + off0[j][c]), s10 = *reinterpret_cast<const S *>(ring + b0[c] + off1[j][c]);
-				const S s01 = *reinterpret_cast<const S *>(ring + b1[c] + off0[j][c]), s11 = *reinterpret_cast<const S *>(ring + b1[c] + off1[j][c]);
-				if constexpr (FAST) {
-					const double h0 = fma(fx[j][c], (double)s10 - (double)s00, (double)s00);
-					const double h1 = fma(fx[j][c], (double)s11 - (double)s01, (double)s01);
-					double xv = fma(fy[c], h1 - h0, h0);
-					xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
-					const double fr = __builtin_amdgcn_fract(xv);
-					S e = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
-					if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS) != 0, 0)) {
-						/* within the recheck band of a rounding boundary: the reference's way, from the source image */
-						if (__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS)
-							e = fixca_codec::exact_linear_sample<S, 3>(reinterpret_cast<const S *>(src), g, min(X0 + PXL * lane + j, W - 1), y, c);
-					}
-					mine[j][2 * c] = e;
-				} else {
-					const double p00 = C::get(s00), p10 = C::get(s10), p01 = C::get(s01), p11 = C::get(s11);
-					/* bilinear(), fix-ca.c:891-893, operation for operation */
-					const double a = __dadd_rn(p00, __dmul_rn(fx[j][c], __dsub_rn(p10, p00)));
-					const double b = __dadd_rn(p01, __dmul_rn(fx[j][c], __dsub_rn(p11, p01)));
-					mine[j][2 * c] = C::put(clip01(__dadd_rn(__dmul_rn(omfy[c], a), __dmul_rn(fy[c], b))));
-				}
+				const double p00 = C::get(*reinterpret_cast<const S *>(ring + b0[c] + off0[j][c]));
+				const double p10 = C::get(*reinterpret_cast<const S *>(ring + b0[c] + off1[j][c]));
+				const double p01 = C::get(*reinterpret_cast<const S *>(ring + b1[c] + off0[j][c]));
+				const double p11 = C::get(*reinterpret_cast<const S *>(ring + b1[c] + off1[j][c]));
+				/* bilinear(), fix-ca.c:891-893, operation for operation */
+				const double a = __dadd_rn(p00, __dmul_rn(fx[j][c], __dsub_rn(p10, p00)));
+				const double b = __dadd_rn(p01, __dmul_rn(fx[j][c], __dsub_rn(p11, p01)));
+				mine[j][2 * c] = C::put(clip01(__dadd_rn(__dmul_rn(omfy[c], a), __dmul_rn(fy[c], b))));
 			}
 		}
 		/* my 24 bytes into the staging row, as dwords (written and read with one type: the compiler orders accesses by type) */
@@ -475,10 +461,7 @@ k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		for (int j = 0; j < PXL; ++j)
 #pragma unroll
 			for (int k = 0; k < 3; ++k) {
-				if constexpr (SB == 2) {
-					const int hw = 3 * j + k;                                  /* halfword of my 24 bytes */
-					w[hw / 2] = (hw & 1) ? (w[hw / 2] | ((uint32_t)mine[j][k] << 16)) : (uint32_t)mine[j][k];
-				} else if constexpr (SB == 4) w[3 * j + k] = __builtin_bit_cast(uint32_t, mine[j][k]);
+				if constexpr (SB == 4) w[3 * j + k] = __builtin_bit_cast(uint32_t, mine[j][k]);
 				else { const unsigned long long q = __builtin_bit_cast(unsigned long long, mine[j][k]); w[2 * k] = (uint32_t)q; w[2 * k + 1] = (uint32_t)(q >> 32); }
 			}
 		asm volatile("" ::: "memory");
@@ -528,7 +511,6 @@ const void *lin_kernel_for(const FixcaGeom *g, int nu, bool fast)
 	if (g->nch == 3) {
 		if (nu != LIN_RGB_NU) return nullptr;
 		switch (g->bpc) {
-		case 2:  return fast ? reinterpret_cast<const void *>(&k_lin_rgb<uint16_t, true>) : nullptr;
 		case 4:  return reinterpret_cast<const void *>(&k_lin_rgb<uint32_t>);
 		case -4: return reinterpret_cast<const void *>(&k_lin_rgb<float>);
 		case -8: return reinterpret_cast<const void *>(&k_lin_rgb<double>);

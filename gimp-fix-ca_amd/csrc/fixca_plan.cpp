@@ -678,16 +678,16 @@ static bool lin_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
 	if (g->interp != 1 || g->bpc == 1) return false;
-	/* RGB: through k_lin_rgb (a lane owns 24 bytes of whole pixels, the row is put together in LDS); 6-byte pixels in
-	 * the weight form only (below) and only when rows are whole dwords */
-	if (g->nch == 3 && g->bpc == 2 && (g->W & 1)) return false;
+	/* RGB: 12- and 24-byte pixels through k_lin_rgb (a lane owns 24 bytes of whole pixels, the row is put together in
+	 * LDS); RGB u16 stays with k_wcol */
+	if (g->nch == 3 && g->bpc == 2) return false;
 	/* 16-bit samples: in the reference's operation order 4 samples per unit, 16 quotients and 70 operations per unit
 	 * and row put the fp64 floor above the memory time (33-40 % against k_wcol's 55 %; FIXCA_LIN_U16=1 to measure): only
 	 * in the weight form, where the planner allows it (not on shifts by halves, where rounding boundaries are common) */
 	const bool fast = g->bpc == 2 && wide_fast_ok(g);
 	/* ... and in a batch: 59.8 against 53.0 % for k_wcol six images per launch; one image per launch the best shape
 	 * only draws (56.4 against 56.7 %), so k_wcol keeps the single call (profiles/r03_sweep_r3u.txt) */
-	if (g->bpc == 2 && !((fast && (flags & FIXCA_PLAN_BATCH)) || (fixca_debug_flag("FIXCA_LIN_U16") && (fast || g->nch == 4)))) return false;
+	if (g->bpc == 2 && !((fast && (flags & FIXCA_PLAN_BATCH)) || fixca_debug_flag("FIXCA_LIN_U16"))) return false;
 	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
 	const long long pitch = (long long)W * pb;
 	if (pitch % 4) return false;
