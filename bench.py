@@ -61,6 +61,7 @@ CONFIGS = [
     dict(name="RGB u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=2, params=dict(PARAMS, interpolation=0), images=8),
     dict(name="RGBA float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=dict(PARAMS, interpolation=1), images=8),
     dict(name="RGBA double linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=dict(PARAMS, interpolation=1), images=4),
+    dict(name="RGB float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=-4, params=dict(PARAMS, interpolation=1), images=8),
 ]
 
 

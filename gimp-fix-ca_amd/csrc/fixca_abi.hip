@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 #include "../../include/fixca_hip.h"
 #include "fixca_geom.h"
@@ -144,8 +145,41 @@ extern "C" int fixca_stream_sync(void *stream)
 	return FIXCA_OK;
 }
 
+/* ---- start-up overlap ---------------------------------------------------------------------------------------------
+ * A PDB call is a fresh process, and the first HIP call in it costs 56-227 ms (runtime and device initialisation,
+ * DESIGN.md §4 "cold-start").  fixca_prewarm() starts that work on a background thread and returns at once, so a
+ * host can call it first thing in run() and spend the time in what it has to do anyway before the pixels are ready
+ * (gegl_buffer_get of the drawable; fixca_cli: reading the file).  The next entry that needs the device joins the
+ * thread.  Calling it is optional, calling it twice is harmless. */
+#include <thread>
+namespace {
+struct Prewarm {
+	std::thread th;
+	bool        started = false;
+	std::mutex  mu;
+	void join() { std::lock_guard<std::mutex> lock(mu); if (th.joinable()) th.join(); }
+	~Prewarm() { if (th.joinable()) th.join(); }        /* a process that exits early must not leave the thread inside the runtime */
+} g_prewarm;
+}
+
+static void prewarm_join(void) { g_prewarm.join(); }
+
+extern "C" void fixca_prewarm(void)
+{
+	std::lock_guard<std::mutex> lock(g_prewarm.mu);
+	if (g_prewarm.started) return;
+	g_prewarm.started = true;
+	g_prewarm.th = std::thread([] {
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return; }
+		(void)hipFree(nullptr);                      /* creates the primary context of device 0 */
+		fixca_phase("prewarm:device_ready");
+	});
+}
+
 static int require_device(void)
 {
+	prewarm_join();
 	int n = fixca_device_count();
 	if (n < 0) return n;
 	if (n == 0) return fixca_fail(FIXCA_E_NODEVICE, "no HIP device visible: the Fix-CA GPU path cannot run");

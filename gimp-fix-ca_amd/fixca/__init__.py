@@ -92,6 +92,7 @@ def _load():
         "fixca_copy_d2h": ([vp, vp, ctypes.c_size_t, vp], ci),
         "fixca_stream_sync": ([vp], ci),
         "fixca_release_cache": ([], None),
+        "fixca_prewarm": ([], None),
         "fixca_time_launches": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, P, cu, vp,
                                  ctypes.POINTER(ctypes.c_double)], ci),
         "fixca_time_copy": ([ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ctypes.c_size_t, vp,

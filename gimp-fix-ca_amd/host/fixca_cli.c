@@ -103,6 +103,7 @@ int main(int argc, char **argv)
 	const char *pos[16];
 
 	fixca_phase("cli:main_entered");           /* after the dynamic loader: libfixca_hip.so, the HIP runtime and their constructors */
+	fixca_prewarm();                           /* what a plug-in does first thing in run(): the runtime initialises while the image is read */
 
 	for (i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--lens-as-float")) lens_float = 1;

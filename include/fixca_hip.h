@@ -137,6 +137,12 @@ FIXCA_API int   fixca_stream_sync(void *stream);
 FIXCA_API void *fixca_host_alloc(size_t nbytes);       /* NULL on failure              */
 FIXCA_API int   fixca_host_free(void *h_ptr);
 FIXCA_API void  fixca_release_cache(void);             /* frees fixca_region_host's buffers and the kernel tables */
+/*
+ * Optional: starts the HIP runtime's initialisation (56-227 ms in a fresh process) on a background thread and
+ * returns at once; the next fixca_region_host / fixca_preview_host joins it.  A plug-in calls it first thing in run()
+ * (fix-ca.c:197), so that the initialisation overlaps with gimp_drawable_get and gegl_buffer_get (fix-ca.c:215, :369).
+ */
+FIXCA_API void  fixca_prewarm(void);
 
 /* ---- the preview caller --------------------------------------------------- */
 /*
