@@ -898,6 +898,44 @@ def test_image_beyond_2gb(torch_cuda, interp, force_fallback, monkeypatch):
     _SCRATCH.clear()
 
 
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_wide_image_beyond_4gb(torch_cuda, interp):
+    """RGBA float 18000 x 16000 = 4.6 GB per buffer: row offsets exceed 2^32.  The LDS-ring kernels of the wide types
+    (k_move, k_lin, k_cub through the batch entry) address a tile's rows through per-tile buffer descriptors with 32-bit
+    offsets relative to them; checked against the fp64 one-thread-per-pixel kernel (64-bit pointers; itself checked against
+    the oracle on every small geometry) over the whole image, and against the oracle on three row bands"""
+    torch = torch_cuda
+    w, h, nch, bpc, sb = 18000, 16000, 4, -4, 4
+    p = fixca.make_params(blue=2.0, red=-2.0, lens_x=7000, lens_y=9000, interpolation=interp)
+    kid, desc = fixca.plan(w, h, nch * sb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
+    assert kid == (8, 9, 10)[interp], desc
+    g = torch.Generator(device="cuda").manual_seed(1234 + interp)
+    src = (torch.rand((h, w, nch), device="cuda", generator=g, dtype=torch.float32) * 1.3 - 0.15).contiguous()
+    raw = src.view(torch.uint8).reshape(h, w, nch * sb)
+    a, b = torch.zeros_like(raw), torch.zeros_like(raw)
+    fixca.fix_ca_batch([raw], [a], w, h, nch * sb, bpc, p)                        # one image through the batch entry: the ring kernel
+    fixca.fix_ca_region(raw, b, w, h, nch * sb, bpc, p, 0, w, 0, h, True, fixca.KERNEL_EXACT)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(a, b))
+    po = pyoracle.make_params(**p.as_dict())
+    for y1 in (0, 8000, h - 48):
+        lo, hi = max(0, y1 - 16), min(h, y1 + 48 + 16)                              # the band and the rows its taps reach
+        band = src[lo:hi].cpu().numpy()
+        pb = pyoracle.make_params(**dict(p.as_dict(), lens_y=p.lens_y - lo))
+        if int(p.lens_y) - lo != int(pb.lens_y):
+            continue
+        # the band alone has another max_dim than the image: compare only when the scale is the image's
+        md_img = max(int(p.lens_x), int(p.lens_y), w - int(p.lens_x), h - int(p.lens_y))
+        md_band = max(int(pb.lens_x), int(pb.lens_y), w - int(pb.lens_x), (hi - lo) - int(pb.lens_y))
+        if md_img != md_band:
+            continue
+        ref = pyoracle.region(band, pb, bpc=bpc, threads=16)
+        got = a[y1:y1 + 48].cpu().numpy().view(np.float32).reshape(48, w, nch)
+        assert got.tobytes() == ref[y1 - lo:y1 - lo + 48].tobytes(), y1
+    del src, raw, a, b
+    torch.cuda.empty_cache()
+
+
 _SCRATCH = {}
 
 
