@@ -918,20 +918,17 @@ def test_wide_image_beyond_4gb(torch_cuda, interp):
     torch.cuda.synchronize()
     assert bool(torch.equal(a, b))
     po = pyoracle.make_params(**p.as_dict())
+    # the oracle on three row bands of the WHOLE geometry (a band cut out and re-centred is not bit-identical: y' is
+    # rounded after adding lens_y).  The host image is allocated untouched - only the bands' pages are ever committed
+    himg = np.empty((h, w, nch), np.float32)
+    hdst = np.empty((h, w, nch), np.float32)
     for y1 in (0, 8000, h - 48):
         lo, hi = max(0, y1 - 16), min(h, y1 + 48 + 16)                              # the band and the rows its taps reach
-        band = src[lo:hi].cpu().numpy()
-        pb = pyoracle.make_params(**dict(p.as_dict(), lens_y=p.lens_y - lo))
-        if int(p.lens_y) - lo != int(pb.lens_y):
-            continue
-        # the band alone has another max_dim than the image: compare only when the scale is the image's
-        md_img = max(int(p.lens_x), int(p.lens_y), w - int(p.lens_x), h - int(p.lens_y))
-        md_band = max(int(pb.lens_x), int(pb.lens_y), w - int(pb.lens_x), (hi - lo) - int(pb.lens_y))
-        if md_img != md_band:
-            continue
-        ref = pyoracle.region(band, pb, bpc=bpc, threads=16)
+        himg[lo:hi] = src[lo:hi].cpu().numpy()
+        pyoracle.region(himg, po, bpc=bpc, y1=y1, y2=y1 + 48, dst=hdst, threads=16)
         got = a[y1:y1 + 48].cpu().numpy().view(np.float32).reshape(48, w, nch)
-        assert got.tobytes() == ref[y1 - lo:y1 - lo + 48].tobytes(), y1
+        assert got.tobytes() == hdst[y1:y1 + 48].tobytes(), y1
+    del himg, hdst
     del src, raw, a, b
     torch.cuda.empty_cache()
 
