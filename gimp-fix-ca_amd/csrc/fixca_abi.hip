@@ -25,11 +25,12 @@ extern "C" hipError_t fixca_launch_roll_batch(const void *const *, void *const *
 extern "C" hipError_t fixca_launch_roll_batch_rgb(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_move_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_lin_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
+extern "C" hipError_t fixca_launch_wide_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 extern "C" hipError_t fixca_launch_cub_batch(const void *const *, void *const *, int, const FixcaGeom *, const FixcaPlan *, hipStream_t);
 #include "fixca_move.h"
 
 /* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (128) per launch, the
- * NONE mover of the wide sample types up to MOVE_BATCH_MAX (32), the other kernels one */
+ * kernels of the wide sample types (k_wcol, k_move, k_lin, k_cub) up to MOVE_BATCH_MAX (32), the other kernels one */
 static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
                        hipStream_t stream, int *launches);
 
@@ -234,11 +235,12 @@ static int launch_many(const void *const *d_src, void *const *d_dst, int n, cons
 			else             HIP_TRY(fixca_launch_roll_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			++count;
 		}
-	} else if ((pl->kernel == FIXCA_K_MOVE || pl->kernel == FIXCA_K_LIN || pl->kernel == FIXCA_K_CUB) && g->y2 > g->y1) {
+	} else if ((pl->kernel == FIXCA_K_MOVE || pl->kernel == FIXCA_K_LIN || pl->kernel == FIXCA_K_CUB || pl->kernel == FIXCA_K_WCOL) && g->y2 > g->y1) {
 		for (int i = 0; i < n; i += MOVE_BATCH_MAX) {
 			const int m = n - i < MOVE_BATCH_MAX ? n - i : MOVE_BATCH_MAX;
 			if (pl->kernel == FIXCA_K_MOVE)     HIP_TRY(fixca_launch_move_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			else if (pl->kernel == FIXCA_K_LIN) HIP_TRY(fixca_launch_lin_batch(d_src + i, d_dst + i, m, g, pl, stream));
+			else if (pl->kernel == FIXCA_K_WCOL) HIP_TRY(fixca_launch_wide_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			else                                HIP_TRY(fixca_launch_cub_batch(d_src + i, d_dst + i, m, g, pl, stream));
 			++count;
 		}

@@ -36,6 +36,7 @@
 #include "fixca_device.h"
 #include "fixca_codec.h"
 #include "fixca_wide.h"
+#include "fixca_move.h"
 #include <mutex>
 #include <type_traits>
 
@@ -174,7 +175,7 @@ __device__ __forceinline__ int tap_index(int c0, int t, int n)
 #endif
 template <typename S, int NCH, int TAPS, int Q, bool ODDW, bool FAST>
 __device__ __forceinline__ void
-wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, const WidePlan &wp)
+wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, const WidePlan &wp, int block)
 {
 	typedef Codec<S> C;
 	constexpr int T = TAPS, BACK = (T == 4) ? 1 : 0;
@@ -205,7 +206,7 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 
 	const int lane = threadIdx.x;
 	const int W = g.W, H = g.H;
-	const int tile = xcd_remap(blockIdx.x, wp.nblocks);
+	const int tile = xcd_remap(block, wp.nblocks);
 	if (tile >= wp.nwaves) return;
 	const int strip = tile % wp.nstrips, chunk = tile / wp.nstrips;
 	const int X0 = strip * wp.oc;
@@ -604,9 +605,13 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 
 template <typename S, int NCH, int TAPS, int Q, bool ODDW>
 __global__ __launch_bounds__(64) WIDE_OCC void
-k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
+k_wcol(MoveBatch imgs, FixcaGeom g, WidePlan wp)
 {
-	wcol_tile<S, NCH, TAPS, Q, ODDW, false>(src, dst, g, wp);
+	/* up to MOVE_BATCH_MAX images of one geometry per launch: block b works on tile b % nblocks of image b / nblocks, so
+	 * the tiles of the next image take the slots the first finishers of this one leave */
+	const int img = blockIdx.x / wp.nblocks;
+	wcol_tile<S, NCH, TAPS, Q, ODDW, false>(reinterpret_cast<const S *>(imgs.src[img]), reinterpret_cast<S *>(imgs.dst[img]), g, wp,
+	                                        (int)blockIdx.x - img * wp.nblocks);
 }
 /* The weight form keeps 16 weights per lane on top of the window and sits at 194 registers; held to 168 (3 waves per
  * SIMD) it spills 9-15 dwords and is still faster: 106 vs 113 us on 6000x4000 RGBA u16. */
@@ -615,9 +620,11 @@ k_wcol(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
 #endif
 template <typename S, int NCH, int Q, bool ODDW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WIDE_WEIGHTS_WAVES))) void
-k_wcol_weights(const S *__restrict__ src, S *__restrict__ dst, FixcaGeom g, WidePlan wp)
+k_wcol_weights(MoveBatch imgs, FixcaGeom g, WidePlan wp)
 {
-	wcol_tile<S, NCH, 4, Q, ODDW, true>(src, dst, g, wp);
+	const int img = blockIdx.x / wp.nblocks;
+	wcol_tile<S, NCH, 4, Q, ODDW, true>(reinterpret_cast<const S *>(imgs.src[img]), reinterpret_cast<S *>(imgs.dst[img]), g, wp,
+	                                    (int)blockIdx.x - img * wp.nblocks);
 }
 
 /* the instantiation a geometry runs: sample type x (interpolation, samples per pixel, odd width); `fast`: the weight
@@ -720,15 +727,27 @@ fixca_wide_device(void)
 }
 
 extern "C" hipError_t
-fixca_launch_wide(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+fixca_launch_wide_batch(const void *const *d_src, void *const *d_dst, int n_images, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
 {
 	if (g->y2 <= g->y1) return hipSuccess;
+	if (n_images < 1 || n_images > MOVE_BATCH_MAX) return hipErrorInvalidValue;
 	if (g->interp < 0 || g->interp > 2) return hipErrorInvalidValue;
 	const void *fn = wcol_kernel_for(g, pl->wide_fast != 0);
 	if (!fn) return hipErrorInvalidValue;
 	WidePlan wp;
 	wp.oc = pl->oc; wp.th = pl->th; wp.nstrips = pl->nstrips; wp.nwaves = pl->nwaves; wp.nblocks = pl->nblocks;
+	MoveBatch imgs;
+	for (int i = 0; i < MOVE_BATCH_MAX; ++i) {
+		imgs.src[i] = static_cast<const unsigned char *>(d_src[i < n_images ? i : 0]);
+		imgs.dst[i] = static_cast<unsigned char *>(d_dst[i < n_images ? i : 0]);
+	}
 	FixcaGeom geom = *g;
-	void *args[] = { &d_src, &d_dst, &geom, &wp };
-	return hipLaunchKernel(fn, dim3((unsigned)wp.nblocks), dim3(64), args, 0, stream);
+	void *args[] = { &imgs, &geom, &wp };
+	return hipLaunchKernel(fn, dim3((unsigned)wp.nblocks * (unsigned)n_images), dim3(64), args, 0, stream);
+}
+
+extern "C" hipError_t
+fixca_launch_wide(const void *d_src, void *d_dst, const FixcaGeom *g, const FixcaPlan *pl, hipStream_t stream)
+{
+	return fixca_launch_wide_batch(&d_src, &d_dst, 1, g, pl, stream);
 }

@@ -451,6 +451,33 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
             assert d.cpu().numpy().tobytes() == pyoracle.region(a, pyoracle.make_params(**p.as_dict()), bpc=bpc).tobytes()
 
 
+@pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
+@pytest.mark.parametrize("nch", [3, 4])
+@pytest.mark.parametrize("interp", [1, 2])
+def test_wide_rolling_kernel_batch_launch(torch_cuda, monkeypatch, bpc, dtype, nch, interp):
+    """k_wcol / k_wcol_weights take up to 32 images of one geometry per launch (block b works on tile b % nblocks of image
+    b / nblocks): 5 and 35 different images (two launches, the second of 3) through the batch entry, every one the oracle's
+    bytes; tiles of 9 rows too (many blocks per image, the last chunk short), an odd width."""
+    torch = torch_cuda
+    w, h = (363, 75) if nch == 4 else (242, 75)
+    sb = abs(bpc)
+    monkeypatch.setenv("FIXCA_NO_LIN", "1")
+    monkeypatch.setenv("FIXCA_NO_CUB", "1")
+    p = fixca.make_params(interpolation=interp, **_scaled(MOVE_PARAMS[3], w, h))
+    kid, desc = fixca.plan(w, h, nch * sb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
+    assert kid == 7, desc
+    po = pyoracle.make_params(**p.as_dict())
+    imgs = [_wide_image(dtype, w, h, nch, 7300 + 11 * k + sb) for k in range(35)]
+    refs = [pyoracle.region(a, po, bpc=bpc).tobytes() for a in imgs]
+    srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]
+    for n, th in ((5, 0), (35, 0), (5, 9)):
+        monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
+        dsts = [torch.full_like(t, 0x3C) for t in srcs[:n]]
+        fixca.fix_ca_batch(srcs[:n], dsts, w, h, nch * sb, bpc, p)
+        torch.cuda.synchronize()
+        for k in range(n):
+            assert dsts[k].cpu().numpy().tobytes() == refs[k], (desc, n, th, k)
+
 @pytest.mark.parametrize("bpc,dtype", [(-4, np.float32), (-8, np.float64)], ids=lambda v: str(v))
 @pytest.mark.parametrize("shape", [(158, 61), (363, 140), (1202, 77), (244, 300), (2050, 33)], ids=str)
 def test_ring_cubic_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, shape):
