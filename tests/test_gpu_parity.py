@@ -465,6 +465,8 @@ def test_wide_rolling_kernel_batch_launch(torch_cuda, monkeypatch, bpc, dtype, n
     monkeypatch.setenv("FIXCA_NO_CUB", "1")
     p = fixca.make_params(interpolation=interp, **_scaled(MOVE_PARAMS[3], w, h))
     kid, desc = fixca.plan(w, h, nch * sb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
+    if bpc == -8 and interp == 1 and nch == 3:
+        pytest.skip("LINEAR on RGB doubles is the one-thread-per-pixel kernel's (plan_wide): " + desc)
     assert kid == 7, desc
     po = pyoracle.make_params(**p.as_dict())
     imgs = [_wide_image(dtype, w, h, nch, 7300 + 11 * k + sb) for k in range(35)]
