@@ -87,9 +87,10 @@ def oracle_diff(np, got, ref):
             "bar": "<= 1 LSB on red/blue (north_star), green/alpha exact"}
 
 
-def cpu_baseline(params_dict):
+def cpu_baseline(params_dict, preview=None):
     """The CPU oracle (the reference's algorithm restated in C, oracle/) timed on this
-    host: 1 thread like the reference, plus an all-cores row-band run as context."""
+    host: 1 thread like the reference, plus an all-cores row-band run as context.
+    preview = (GPU window, its parameters): the same preview call on the oracle, timed and compared."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import pyoracle
@@ -117,12 +118,45 @@ def cpu_baseline(params_dict):
                 break
     except OSError:
         pass
-    return {
+    out = {
         "value": round(W * H / best / 1e6, 2), "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": "3 passes over image 0 of the batch (6000x4000 RGBA8 noise, 24 Mpx each), best pass, gcc -O2 no -march",
         "all_cores": {"value": round(W * H / best_mt / 1e6, 1), "threads": nthr},
         "host": {"cpu": model, "nproc": ncpu},
-    }, dst
+    }
+    if preview is not None:
+        got, pdict = preview
+        x, y, w, h = PREVIEW_WINDOW
+        pp = pyoracle.make_params(**pdict)
+        t = time.perf_counter()
+        full = pyoracle.region(img, pp, y1=y, y2=y + h, show_progress=0, dst=dst)     # what preview_update asks of fix_ca_region (fix-ca.c:656)
+        want = pyoracle.preview(full, 1, x, y, w, h)
+        ms = (time.perf_counter() - t) * 1e3
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        out["preview_call"] = {"ms": round(ms, 1), "cores": 1, "gpu_window_max_abs_diff": int(d.max()),
+                               "green_alpha_equal": bool(np.array_equal(got[..., 1], want[..., 1]) and np.array_equal(got[..., 3], want[..., 3]))}
+    return out, dst
+
+
+PREVIEW_WINDOW = (2744, 1744, 512, 512)     # x, y, width, height of the preview window in the 6000x4000 image
+
+
+def preview_calls(np, fixca, himg):
+    """preview_update()'s pixel work (fix-ca.c:647-671) through fixca_preview_host, as a slider drag makes it: every
+    call has a new parameter block (new tables), uploads the rows the window's rows reach, corrects full-width rows
+    [y, y + height) with show_progress FALSE (centre lines), crops the window and downloads it.  Host wall time."""
+    x, y, w, h = PREVIEW_WINDOW
+    times, out, last = [], None, None
+    for k in range(6):
+        last = dict(PARAMS, blue=2.0 + 0.25 * k, red=-2.0 - 0.125 * k)
+        p = fixca.make_params(**last)
+        t = time.perf_counter()
+        out = fixca.preview(himg, p, 1, x, y, w, h)
+        times.append((time.perf_counter() - t) * 1e3)
+    times = sorted(times[1:])                                   # the first call allocates
+    return {"ms": round(times[len(times) // 2], 3), "window": list(PREVIEW_WINDOW), "calls": 5,
+            "what": "fixca_preview_host on the host image, a new parameter block per call (slider drag): upload of the rows in reach, "
+                    "rows y..y+height corrected at full width, centre lines, crop, download; median host wall time"}, out, last
 
 
 def sample_bytes(bpc):
@@ -427,6 +461,7 @@ def main():
     # ---- not timed: sanity of what was just computed (every rank), yardsticks, CPU baseline (rank 0) ----
     ok = True
     extra = {}
+    pv_img = pv_params = None
     checks = {}
     exact = torch.empty_like(srcs[0])
     worst, differing = 0, 0
@@ -497,6 +532,9 @@ def main():
             del d0, batch0
             fixca.pinned_free(psrc)
             fixca.pinned_free(pdst)
+            # (3b) the second caller: preview_update()'s calls while a slider is dragged
+            pv, pv_img, pv_params = preview_calls(np, fixca, hsrc.reshape(H, W, C))
+            extra["preview_call"] = pv
             # (4) a PDB call is a fresh process: what that costs from start to exit
             cc = cold_call(torch, hsrc)
             if isinstance(cc, tuple):
@@ -547,8 +585,16 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = run_configs(torch, fixca, dev, P)
         if world == 1 and not args.no_cpu_baseline:
-            cb, ref = cpu_baseline(PARAMS)
+            cb, ref = cpu_baseline(PARAMS, (pv_img, pv_params) if pv_img is not None else None)
             out["cpu_baseline"] = cb
+            if "preview_call" in cb:
+                pc = cb.pop("preview_call")
+                out["preview_call"]["cpu_oracle_ms"] = pc["ms"]
+                out["preview_call"]["vs_oracle"] = {k: pc[k] for k in ("gpu_window_max_abs_diff", "green_alpha_equal")}
+                good = pc["gpu_window_max_abs_diff"] <= 1 and pc["green_alpha_equal"]
+                out["checks"]["preview_within_1_lsb_of_cpu_oracle"] = bool(good)
+                out["ok"] = bool(out["ok"] and good)
+                ok = ok and good
         print(json.dumps(out), flush=True)
 
     if world > 1:
