@@ -129,7 +129,10 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	};
 	row_tables(0);
 	const int yl = Y0 + nrows - 1;
-	const int keep0 = min(Y0, min(cub_clamp(__builtin_amdgcn_readlane(y0_v[0], 0) - 1, H), cub_clamp(__builtin_amdgcn_readlane(y0_v[1], 0) - 1, H)));
+	/* readfirstlane: the value is wave-uniform, but the compiler computes it on the vector unit (it moves the readlane up
+	 * to the lane id and redoes the fp64 map there), builds the source descriptor in vector registers and then wraps every
+	 * LDS-DMA instruction in a waterfall loop (4 readfirstlane, 2 compares, saveexec, branch per issue) */
+	const int keep0 = __builtin_amdgcn_readfirstlane(min(Y0, min(cub_clamp(__builtin_amdgcn_readlane(y0_v[0], 0) - 1, H), cub_clamp(__builtin_amdgcn_readlane(y0_v[1], 0) - 1, H))));
 	int lastneed = yl;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lastneed = max(lastneed, cub_clamp((int)floor(map_dbl(yl, g.yc, H, g.s[c], g.ys[c])) + 2, H));

@@ -138,7 +138,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	};
 	row_tables(0);
 	const int yl = Y0 + nrows - 1;
-	const int keep0 = min(Y0, min(__builtin_amdgcn_readlane(r0_v[0], 0), __builtin_amdgcn_readlane(r0_v[1], 0)));
+	const int keep0 = __builtin_amdgcn_readfirstlane(min(Y0, min(__builtin_amdgcn_readlane(r0_v[0], 0), __builtin_amdgcn_readlane(r0_v[1], 0))));   /* readfirstlane: see k_cub */
 	int lastneed = yl;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lastneed = max(lastneed, min((int)floor(map_dbl(yl, g.yc, H, g.s[c], g.ys[c])) + 1, H - 1));
@@ -374,7 +374,7 @@ k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	};
 	row_tables(0);
 	const int yl = Y0 + nrows - 1;
-	const int keep0 = min(Y0, min(__builtin_amdgcn_readlane(r0_v[0], 0), __builtin_amdgcn_readlane(r0_v[1], 0)));
+	const int keep0 = __builtin_amdgcn_readfirstlane(min(Y0, min(__builtin_amdgcn_readlane(r0_v[0], 0), __builtin_amdgcn_readlane(r0_v[1], 0))));   /* readfirstlane: see k_cub */
 	int lastneed = yl;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) lastneed = max(lastneed, min((int)floor(map_dbl(yl, g.yc, H, g.s[c], g.ys[c])) + 1, H - 1));

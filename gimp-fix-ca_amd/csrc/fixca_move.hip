@@ -145,6 +145,11 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	};
 	row_tables(0);
 	const int yl = Y0 + nrows - 1;
+	/* Not forced into a scalar register (k_lin and k_cub do that): the compiler then keeps the source descriptor in vector
+	 * registers and wraps every LDS-DMA instruction in a one-pass waterfall loop.  For the mover that measures the same or
+	 * better than the plain instruction (one image per launch, RGBA float: 74.0-75.2 against 72.0-73.2 % on three boxes;
+	 * batched u16 67.4 against 66.6 %; everything else within 0.2 points; pacing the issues with s_sleep does not
+	 * reproduce it: profiles/r03_sweep_r3t_waterfall.txt), so it stays as the compiler builds it. */
 	const int keep0 = min(Y0, min(__builtin_amdgcn_readlane(rowR_v, 0), __builtin_amdgcn_readlane(rowB_v, 0)));
 	const int lastneed = max(yl, max(map_int(yl, g.yc, H, g.s[0], g.ys[0]), map_int(yl, g.yc, H, g.s[1], g.ys[1])));
 	const int lastneed_s = __builtin_amdgcn_readfirstlane(lastneed);

@@ -99,3 +99,18 @@ def test_ring_loads_are_lds_dma_and_scalar_tables(roll_asm):
     assert re.search(r"buffer_load_dwordx4 .* lds", text)          # LDS-DMA ring fill
     assert "s_load_dwordx" in text                                 # block descriptors / weights via SMEM
     assert "v_readlane_b32" not in text                            # 3x the cost of a VALU op: tables replaced them
+
+
+@pytest.mark.parametrize("source", ["fixca_roll.hip", "fixca_lin.hip", "fixca_cub.hip"])
+def test_ring_loads_are_not_wrapped_in_waterfall_loops(tmp_path_factory, source):
+    """An LDS-DMA instruction takes its buffer descriptor from scalar registers.  When the compiler holds the descriptor in
+    vector registers (round 3: the first source row of a tile, wave-uniform but computed with fp64 vector instructions) it
+    wraps every such load in a loop of 4 v_readfirstlane, 2 compares, saveexec and a branch: 1.5-3 points of the HBM peak
+    on the LINEAR kernels.  k_lin and k_cub force the value into a scalar register; this keeps it that way.
+    (k_move is left as the compiler builds it: see the comment there.)"""
+    asm = _asm(tmp_path_factory, source)
+    dma = [i for i, l in enumerate(asm) if re.search(r"buffer_load_dword\S*\s.*\blds\b", l)]
+    assert len(dma) >= 8, "no LDS-DMA found in " + source
+    for i in dma:
+        before = " ".join(asm[max(0, i - 3):i])
+        assert "saveexec" not in before, (source, asm[max(0, i - 8):i + 1])
