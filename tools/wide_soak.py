@@ -1,6 +1,8 @@
 """GPU box: soak of the 16-bit weight forms (k_wcol_weights: CUBIC; k_lin<u16, FAST>: LINEAR with SOAK_INTERP=1) against the one-thread-per-pixel fp64 kernel: N random parameter
 sets (lateral amounts up to the plug-in's +-30, lens anywhere, some with directional shifts) on 6000x4000 RGBA / RGB u16
 images of four kinds (noise, smooth ramps, ramps with a little noise, random 0 / 65535 steps).  Every sample must be identical.
+SOAK_BATCH=1: through the batch entry (two result images per call), where k_wcol runs several images per launch and 16-bit
+LINEAR takes k_lin's weight form by itself.
 usage: wide_soak.py [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,13 +34,20 @@ for it in range(N):
     if it % 5 == 0:
         kw.update(x_blue=float(rng.uniform(-mag, mag)), y_red=float(rng.uniform(-mag, mag)))
     p = fixca.make_params(interpolation=int(os.environ.get("SOAK_INTERP", "2")), **kw)
-    desc = fixca.plan(W, H, nch * 2, 2, p)[1]
+    batch = os.environ.get("SOAK_BATCH", "0") == "1"
+    desc = fixca.plan(W, H, nch * 2, 2, p, kernel=fixca.KERNEL_AUTO | (fixca.PLAN_BATCH if batch else 0))[1]
     weights_runs += "weights+recheck" in desc
     a = torch.zeros_like(raw); b = torch.zeros_like(raw)
-    fixca.fix_ca_region(raw, a, W, H, nch * 2, 2, p, 0, W, 0, H, True, fixca.KERNEL_AUTO)
+    if batch:
+        a2 = torch.zeros_like(raw)
+        fixca.fix_ca_batch([raw, raw], [a, a2], W, H, nch * 2, 2, p)
+    else:
+        fixca.fix_ca_region(raw, a, W, H, nch * 2, 2, p, 0, W, 0, H, True, fixca.KERNEL_AUTO)
     fixca.fix_ca_region(raw, b, W, H, nch * 2, 2, p, 0, W, 0, H, True, fixca.KERNEL_EXACT)
     torch.cuda.synchronize()
     d = int((a.view(torch.int16) != b.view(torch.int16)).sum())
+    if batch:
+        d += int((a2.view(torch.int16) != b.view(torch.int16)).sum())
     total += H * W * 2; bad += d
     print("%2d nch=%d kind=%d %-60s differing %d  [%s]" % (it, nch, kind, str({k: round(v, 3) for k, v in kw.items()})[:60], d, desc[-40:]), flush=True)
 print("red/blue samples compared: %d, differing: %d, runs on the weight form: %d of %d" % (total, bad, weights_runs, N))
