@@ -1,0 +1,119 @@
+"""GPU box: randomised parity soak of the whole C-ABI pixel path against the CPU oracle (oracle/: test infrastructure).
+
+Every case draws an image size (8 .. 3200 columns, 1 .. 900 rows), a pixel format (u8 / u16 / u32 / float / double samples,
+RGB or RGBA), an interpolation, a parameter block (lateral amounts up to the plug-in's +-30, lens centre anywhere including
+outside the image, directional shifts, whole-pixel shifts, nearly-1 scales), a row range, and an entry: the device entry on one
+image, or the batch entry on 2 .. 5 different images (where the batched kernels and the 16-bit weight forms run).  The result
+must be the oracle's: bit for bit for NONE and for every sample type wider than 8 bits, within 1 LSB on red / blue (green and
+alpha equal, at most 2 % of the samples differing; 30 % for pure shifts by halves and quarters, where the exact value of every
+few samples IS a rounding boundary k + 1/2 and the reference's own fp64 rounding noise decides) for 8-bit LINEAR / CUBIC; rows
+outside the range untouched.
+
+    python tools/fuzz_soak.py [cases=600] [seed=1]        ->  one line per failure, a table by kernel at the end, rc 1 on failure
+"""
+import os, sys, time, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gimp-fix-ca_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch, fixca, pyoracle
+from fixca import synth
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+FORMATS = [(1, np.uint8), (2, np.uint16), (4, np.uint32), (-4, np.float32), (-8, np.float64)]
+THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+rng = np.random.default_rng(0xF0220000 + SEED)
+
+
+def image(dtype, w, h, nch, seed):
+    raw = synth.noise_bytes(seed, w * h * nch * 8).view(np.uint64)[: w * h * nch]
+    if np.issubdtype(dtype, np.integer):
+        return (raw & np.uint64(np.iinfo(dtype).max)).astype(dtype).reshape(h, w, nch)
+    v = (raw >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return (v * 1.3 - 0.15).astype(dtype).reshape(h, w, nch)          # floats: mostly in [0, 1], some outside (clipped by LINEAR / CUBIC)
+
+
+def params(w, h, interp):
+    mag = [0.05, 0.3, 1.0, 3.0, 10.0, 30.0][int(rng.integers(0, 6))]
+    kw = dict(blue=float(rng.uniform(-mag, mag)), red=float(rng.uniform(-mag, mag)),
+              lens_x=float(rng.integers(-2, w + 2)), lens_y=float(rng.integers(-2, h + 2)))
+    r = int(rng.integers(0, 8))
+    if r == 0:
+        kw.update(lens_x=-1.0, lens_y=-1.0)                              # the plug-in's default: the image centre
+    if r in (1, 2):
+        kw.update(x_blue=float(rng.uniform(-mag, mag)), x_red=float(rng.uniform(-mag, mag)))
+    if r in (2, 3):
+        kw.update(y_blue=float(rng.uniform(-mag, mag)), y_red=float(rng.uniform(-mag, mag)))
+    if r == 4:                                                           # whole-pixel shifts: every fraction exactly 0
+        kw.update(blue=0.0, red=0.0, x_blue=float(rng.integers(-4, 5)), y_red=float(rng.integers(-4, 5)), y_blue=float(rng.integers(-2, 3)))
+    if r == 5:                                                           # halves and quarters: rounding boundaries are common
+        kw.update(blue=0.0, red=0.0, x_blue=float(rng.integers(-8, 9)) / 4.0, y_red=float(rng.integers(-8, 9)) / 4.0)
+    return fixca.make_params(interpolation=interp, **kw), kw, r in (4, 5)
+
+
+stats = collections.defaultdict(lambda: [0, 0, 0])          # kernel text -> cases, samples, failures
+fails = 0
+t0 = time.time()
+for it in range(N):
+    bpc, dtype = FORMATS[int(rng.integers(0, 5))]
+    nch = int(rng.integers(3, 5))
+    sb = abs(bpc)
+    big = it % 5 == 0
+    w = int(rng.integers(600, 3201)) if big else int(rng.integers(8, 700))
+    h = int(rng.integers(100, 901)) if big else int(rng.integers(1, 160))
+    if bpc == 1 and it % 3:
+        w = max(8, w & ~3)
+    interp = int(rng.integers(0, 3))
+    p, kw, on_grid = params(w, h, interp)
+    nimg = 1 if it % 3 else int(rng.integers(2, 6))
+    y1, y2 = (0, h) if (nimg > 1 or it % 2) else (int(rng.integers(0, h)), 0)
+    if y2 == 0:
+        y2 = int(rng.integers(y1 + 1, h + 1))
+    try:
+        kid, desc = fixca.plan(w, h, nch * sb, bpc, p, y1=y1, y2=y2, kernel=fixca.KERNEL_AUTO | (fixca.PLAN_BATCH if nimg > 1 else 0))
+    except fixca.FixCaError as e:
+        if e.code != fixca.E_DOMAIN:                          # max_dim + amount <= 0 is the one refusal allowed here
+            print("case %d: plan refused %dx%d bpc=%d nch=%d interp=%d %s: %s" % (it, w, h, bpc, nch, interp, kw, e), flush=True)
+            fails += 1
+        continue
+    imgs = [image(dtype, w, h, nch, 0xF0220000 + 7 * it + k) if bpc != 1 else synth.noise_image(0xF0220000 + 7 * it + k, w, h, nch) for k in range(nimg)]
+    po = pyoracle.make_params(**p.as_dict())
+    srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]
+    dsts = [torch.full_like(t, 0x6B) for t in srcs]
+    if nimg > 1:
+        fixca.fix_ca_batch(srcs, dsts, w, h, nch * sb, bpc, p)
+    else:
+        fixca.fix_ca_region(srcs[0], dsts[0], w, h, nch * sb, bpc, p, 0, w, y1, y2, True)
+    torch.cuda.synchronize()
+    key = desc.split(" bpp=")[0] + (" weights" if "weights" in desc else "") + (" batch" if nimg > 1 else "")
+    st = stats[key]
+    st[0] += 1
+    for a, d in zip(imgs, dsts):
+        ref = pyoracle.region(a, po, bpc=bpc, y1=y1, y2=y2, threads=THREADS if w * (y2 - y1) > 200000 else 1)
+        got = d.cpu().numpy()
+        refb = ref.view(np.uint8).reshape(h, w, nch * sb)
+        st[1] += (y2 - y1) * w * 2
+        bad = None
+        if not (np.all(got[:y1] == 0x6B) and np.all(got[y2:] == 0x6B)):
+            bad = "rows outside [y1, y2) touched"
+        elif bpc != 1 or interp == 0:
+            if got[y1:y2].tobytes() != refb[y1:y2].tobytes():
+                bad = "%d differing bytes" % int((got[y1:y2] != refb[y1:y2]).sum())
+        else:
+            df = np.abs(got[y1:y2].astype(np.int16) - refb[y1:y2].astype(np.int16))
+            g = got[y1:y2].reshape(y2 - y1, w, nch)
+            r = refb[y1:y2].reshape(y2 - y1, w, nch)
+            if df.max() > 1 or int((df != 0).sum()) > (0.30 if on_grid else 0.02) * df.size + 8 or not np.array_equal(g[..., 1], r[..., 1]) or (nch == 4 and not np.array_equal(g[..., 3], r[..., 3])):
+                bad = "max diff %d, %d differing" % (int(df.max()), int((df != 0).sum()))
+        if bad:
+            fails += 1
+            st[2] += 1
+            print("case %d FAILED (%s): %dx%d bpc=%d nch=%d interp=%d rows %d..%d images %d %s [%s]" % (it, bad, w, h, bpc, nch, interp, y1, y2, nimg, kw, desc), flush=True)
+            break
+    if it % 100 == 99:
+        print("... %d cases, %d failures, %.0f s" % (it + 1, fails, time.time() - t0), flush=True)
+print("%-44s %7s %14s %8s" % ("kernel (entry)", "cases", "red/blue smp", "failures"))
+for k in sorted(stats):
+    print("%-44s %7d %14d %8d" % (k, *stats[k]))
+print("cases %d (seed %d), failures %d, %.0f s" % (N, SEED, fails, time.time() - t0))
+sys.exit(1 if fails else 0)
