@@ -7,7 +7,9 @@ image, or the batch entry on 2 .. 5 different images (where the batched kernels 
 must be the oracle's: bit for bit for NONE and for every sample type wider than 8 bits, within 1 LSB on red / blue (green and
 alpha equal, at most 2 % of the samples differing; 30 % for pure shifts by halves and quarters, where the exact value of every
 few samples IS a rounding boundary k + 1/2 and the reference's own fp64 rounding noise decides) for 8-bit LINEAR / CUBIC; rows
-outside the range untouched.
+outside the range untouched.  One case in five goes through the host entry on host images instead (fixca_region_host, half of
+them with show_progress FALSE: the lens-centre lines), one in ten through the preview entry (fixca_preview_host: rows of a
+random window, centre lines, crop, 8-bit down-conversion) against the oracle's preview.
 
     python tools/fuzz_soak.py [cases=600] [seed=1]        ->  one line per failure, a table by kernel at the end, rc 1 on failure
 """
@@ -78,6 +80,46 @@ for it in range(N):
         continue
     imgs = [image(dtype, w, h, nch, 0xF0220000 + 7 * it + k) if bpc != 1 else synth.noise_image(0xF0220000 + 7 * it + k, w, h, nch) for k in range(nimg)]
     po = pyoracle.make_params(**p.as_dict())
+    if nimg == 1 and it % 10 == 7:
+        # the preview entry: window (x, y, pw, ph); 8-bit LINEAR / CUBIC within 1 LSB, everything else equal
+        pw, ph = int(rng.integers(1, w + 1)), y2 - y1
+        x = int(rng.integers(0, w - pw + 1))
+        got = fixca.preview(imgs[0], p, bpc, x, y1, pw, ph)
+        full = pyoracle.region(imgs[0], po, bpc=bpc, y1=y1, y2=y2, show_progress=0)
+        want = pyoracle.preview(full, bpc, x, y1, pw, ph)
+        st = stats["preview entry (" + desc.split(" bpp=")[0] + ")"]
+        st[0] += 1
+        st[1] += pw * ph * 2
+        df = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        lim = 1 if (bpc == 1 and interp != 0) else 0
+        if got.shape != want.shape or df.max() > lim:
+            fails += 1
+            st[2] += 1
+            print("case %d FAILED (preview, max diff %d): %dx%d bpc=%d nch=%d interp=%d window %d,%d %dx%d %s [%s]" % (it, int(df.max()), w, h, bpc, nch, interp, x, y1, pw, ph, kw, desc), flush=True)
+        continue
+    if nimg == 1 and it % 5 == 3:
+        # the host entry on host images; every other one as the preview calls it (show_progress FALSE: centre lines)
+        sp = bool(it % 2)
+        out = np.full_like(imgs[0], 0) if bpc != 1 else np.full_like(imgs[0], 0x6B)
+        out.view(np.uint8)[...] = 0x6B
+        fixca.fix_ca_region(imgs[0], out, w, h, nch * sb, bpc, p, 0, w, y1, y2, sp)
+        ref = np.empty_like(imgs[0])
+        ref.view(np.uint8)[...] = 0x6B
+        pyoracle.region(imgs[0], po, bpc=bpc, y1=y1, y2=y2, show_progress=1 if sp else 0, dst=ref)
+        st = stats["host entry%s (%s)" % ("" if sp else ", centre lines", desc.split(" bpp=")[0])]
+        st[0] += 1
+        st[1] += (y2 - y1) * w * 2
+        gb, rb = out.view(np.uint8).reshape(h, -1), ref.view(np.uint8).reshape(h, -1)
+        if bpc != 1 or interp == 0:
+            bad = None if gb.tobytes() == rb.tobytes() else "%d differing bytes" % int((gb != rb).sum())
+        else:
+            df = np.abs(gb.astype(np.int16) - rb.astype(np.int16))
+            bad = None if df.max() <= 1 and int((df != 0).sum()) <= (0.30 if on_grid else 0.02) * df.size + 8 else "max diff %d, %d differing" % (int(df.max()), int((df != 0).sum()))
+        if bad:
+            fails += 1
+            st[2] += 1
+            print("case %d FAILED (host entry, %s): %dx%d bpc=%d nch=%d interp=%d rows %d..%d show_progress=%d %s [%s]" % (it, bad, w, h, bpc, nch, interp, y1, y2, sp, kw, desc), flush=True)
+        continue
     srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]
     dsts = [torch.full_like(t, 0x6B) for t in srcs]
     if nimg > 1:
