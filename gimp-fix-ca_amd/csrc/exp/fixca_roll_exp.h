@@ -7,7 +7,8 @@
  *   acc[0] outside blocks   acc[1] fetch: DMA issue + vmcnt wait   acc[2] ring reads issued and landed
  *   acc[3] filter arithmetic   acc[4] conversions + store issue   acc[5] prologue (tables, first ring fill)
  * and writes 8 x u64 per workgroup to the start of the image: acc[0..3], start (100 MHz ticks), lifetime
- * (100 MHz ticks), total shader cycles, gen flag.  tools/stamps.py prints the summary.
+ * (100 MHz ticks), total shader cycles, and a tag: gen flag | strip << 8 | first row << 20 | XCC id << 40 | HW_ID[15:4] << 44.
+ * tools/stamps.py prints the summary.
  */
 #ifndef FIXCA_ROLL_EXP_H
 #define FIXCA_ROLL_EXP_H
@@ -31,7 +32,8 @@
 			unsigned long long v_ = (st).acc[0]; \
 			for (int i_ = 1; i_ < 8; ++i_) v_ = ((lane) == i_) ? (st).acc[i_] : v_; \
 			if ((lane) == 6) v_ = (st).last - (st).t_begin; \
-			if ((lane) == 7) v_ = (gen); \
+			if ((lane) == 7) v_ = (gen) | ((unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15u) << 40) /* HW_REG_XCC_ID[3:0] */ \
+				| ((unsigned long long)((__builtin_amdgcn_s_getreg(63492) >> 4) & 0xfffu) << 44); /* HW_REG_HW_ID[15:4]: SIMD, CU, SH, SE */ \
 			if ((lane) == 5) v_ = __builtin_amdgcn_s_memrealtime() - (st).rt_begin; \
 			if ((lane) == 4) v_ = (st).rt_begin; \
 			reinterpret_cast<unsigned long long *>(dst)[(size_t)blockIdx.x * 8 + (lane)] = v_; \

@@ -633,7 +633,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	STAMP(5);                                       /* prologue */
 	if (hd.gen) run(std::integral_constant<int, 5>{});
 	else        run(std::integral_constant<int, (T == 1) ? 2 : T>{});
-	ROLL_EXP_END(st, dst, lane, hd.gen);
+	ROLL_EXP_END(st, dst, lane, (unsigned long long)hd.gen | ((unsigned long long)strip << 8) | ((unsigned long long)Y0 << 20));
 }
 
 /* build option: hold the kernel to the registers that let N waves share a SIMD (-DROLL_WAVES_PER_EU=3: 168) */
