@@ -182,15 +182,35 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		else cub_wait_vm<0>();
 	};
 
+	/* Away from the left and right edge of the image the four taps of a sample are four consecutive pixels: one address and
+	 * constant offsets (the compiler pairs the reads: ds_read2) instead of four addresses.  Wave-uniform: a tile in which
+	 * any lane has a clamped tap takes the general form for all of its rows. */
+	bool contig_l = true;
+#pragma unroll
+	for (int i = 0; i < NU; ++i)
+#pragma unroll
+		for (int j = 0; j < NC; ++j)
+#pragma unroll
+			for (int t = 1; t < 4; ++t) contig_l = contig_l && off[i][j][t] == off[i][j][0] + (uint32_t)(t * PB);
+	const bool contig = __builtin_amdgcn_ballot_w64(!contig_l) == 0;
+
 	/* cubicY of one source row for computed sample (i, j): the row is given by its ring base (bR / bB: red's / blue's) */
-	auto hrow = [&](int i, int j, uint32_t bR, uint32_t bB) -> double {
+	auto hrow = [&](auto contig_tag, int i, int j, uint32_t bR, uint32_t bB) -> double {
+		constexpr bool CONTIG = decltype(contig_tag)::value;
 		const uint32_t base = (SB == 8) ? (blue[i] ? bB : bR) : ((j & 1) ? bB : bR);
 		S s[4];
+		if constexpr (CONTIG) {
+			const S *p = reinterpret_cast<const S *>(ring + base + off[i][j][0]);
 #pragma unroll
-		for (int t = 0; t < 4; ++t) s[t] = *reinterpret_cast<const S *>(ring + base + off[i][j][t]);
+			for (int t = 0; t < 4; ++t) s[t] = p[t * 4];                                         /* 4 samples per RGBA pixel */
+		} else {
+#pragma unroll
+			for (int t = 0; t < 4; ++t) s[t] = *reinterpret_cast<const S *>(ring + base + off[i][j][t]);
+		}
 		return cr_exact(C::get(s[0]), C::get(s[1]), C::get(s[2]), C::get(s[3]), fx[i][j]);              /* fix-ca.c:905-907 */
 	};
 
+	auto rows_loop = [&](auto contig_tag) {
 	double hh[NU][NC][4];                              /* the rolling windows: 4 horizontally filtered rows per computed sample */
 	int    y0prev[2] = { -1000000, -1000000 };
 	uint32_t so_st = 0;
@@ -217,7 +237,7 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 			for (int i = 0; i < NU; ++i)
 #pragma unroll
 				for (int j = 0; j < NC; ++j) {
-					const double nw = hrow(i, j, bR, bB);
+					const double nw = hrow(contig_tag, i, j, bR, bB);
 					hh[i][j][0] = hh[i][j][1]; hh[i][j][1] = hh[i][j][2]; hh[i][j][2] = hh[i][j][3]; hh[i][j][3] = nw;
 				}
 		} else {
@@ -229,7 +249,7 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 				for (int i = 0; i < NU; ++i)
 #pragma unroll
-					for (int j = 0; j < NC; ++j) hh[i][j][t] = hrow(i, j, bR, bB);
+					for (int j = 0; j < NC; ++j) hh[i][j][t] = hrow(contig_tag, i, j, bR, bB);
 			}
 		}
 		y0prev[0] = y0[0]; y0prev[1] = y0[1];
@@ -260,6 +280,9 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		so_st += pitch;
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the next row's DMA may overwrite what was read here */
 	}
+	};
+	if (contig) rows_loop(std::true_type{});
+	else        rows_loop(std::false_type{});
 }
 
 template <typename S>
