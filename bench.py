@@ -50,9 +50,9 @@ CONFIGS = [
     dict(name="config4 directional cubic, 8192x8192 RGBA8", w=8192, h=8192, c=4, bpc=1,
          params=dict(lens_x=4096, lens_y=4096, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0, interpolation=2)),
     dict(name="RGB8 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=1, params=PARAMS),
-    dict(name="RGBA u16 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=PARAMS, images=16),
+    dict(name="RGBA u16 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=PARAMS, images=32),
     dict(name="RGBA float cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=PARAMS, images=16),
-    dict(name="RGBA u16 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=1), images=16),
+    dict(name="RGBA u16 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=1), images=32),
     dict(name="RGBA u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=0), images=16),
     dict(name="RGBA double cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=PARAMS, images=8),
     dict(name="RGBA u32 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=dict(PARAMS, interpolation=0), images=16),
