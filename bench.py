@@ -50,18 +50,18 @@ CONFIGS = [
     dict(name="config4 directional cubic, 8192x8192 RGBA8", w=8192, h=8192, c=4, bpc=1,
          params=dict(lens_x=4096, lens_y=4096, x_blue=1.0, x_red=0.0, y_blue=-7.5, y_red=4.0, interpolation=2)),
     dict(name="RGB8 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=1, params=PARAMS),
-    dict(name="RGBA u16 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=PARAMS, images=32),
-    dict(name="RGBA float cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=PARAMS, images=16),
-    dict(name="RGBA u16 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=1), images=32),
-    dict(name="RGBA u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=0), images=16),
-    dict(name="RGBA double cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=PARAMS, images=8),
-    dict(name="RGBA u32 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=dict(PARAMS, interpolation=0), images=16),
-    dict(name="RGBA float none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=dict(PARAMS, interpolation=0), images=16),
-    dict(name="RGBA double none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=dict(PARAMS, interpolation=0), images=8),
-    dict(name="RGB u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=2, params=dict(PARAMS, interpolation=0), images=16),
-    dict(name="RGBA float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=dict(PARAMS, interpolation=1), images=16),
-    dict(name="RGBA double linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=dict(PARAMS, interpolation=1), images=8),
-    dict(name="RGB float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=-4, params=dict(PARAMS, interpolation=1), images=16),
+    dict(name="RGBA u16 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=PARAMS, images=64),
+    dict(name="RGBA float cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=PARAMS, images=32),
+    dict(name="RGBA u16 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=1), images=64),
+    dict(name="RGBA u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=2, params=dict(PARAMS, interpolation=0), images=64),
+    dict(name="RGBA double cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=PARAMS, images=16),
+    dict(name="RGBA u32 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=dict(PARAMS, interpolation=0), images=32),
+    dict(name="RGBA float none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=dict(PARAMS, interpolation=0), images=32),
+    dict(name="RGBA double none, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=dict(PARAMS, interpolation=0), images=16),
+    dict(name="RGB u16 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=2, params=dict(PARAMS, interpolation=0), images=64),
+    dict(name="RGBA float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=dict(PARAMS, interpolation=1), images=32),
+    dict(name="RGBA double linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=dict(PARAMS, interpolation=1), images=16),
+    dict(name="RGB float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=-4, params=dict(PARAMS, interpolation=1), images=32),
 ]
 
 
@@ -164,7 +164,7 @@ def sample_bytes(bpc):
 
 
 KID_ROLL = 6                     # fixca_plan_describe's id of the row-rolling kernel (include/fixca_hip.h)
-KID_WCOL = 7                     # ... of the fp64 rolling-window kernel of the wide sample types: up to 32 images per launch
+KID_WCOL = 7                     # ... of the fp64 rolling-window kernel of the wide sample types: up to 128 images per launch
 KID_MOVE = 8                     # ... of the NONE byte mover of the wide sample types: likewise
 KID_LIN = 9                      # ... of the LDS-ring LINEAR kernel of the wide RGBA formats: likewise
 KID_CUB = 10                     # ... of the LDS-ring CUBIC kernel of the wide RGBA formats: likewise
@@ -248,8 +248,8 @@ def run_configs(torch, fixca, dev, per_launch):
             else:
                 dt = torch.float32 if bpc == -4 else torch.float64
                 md = float((dsts[0].view(dt).to(torch.float64) - exact.view(dt).to(torch.float64)).abs().max())
-            # the row-rolling kernel (plan id 6) takes up to per_launch images in one launch, the kernels of the wide sample types (7 - 10) up to 32; every other kernel is one launch per image
-            ipl = min(n, per_launch) if kid == KID_ROLL else min(n, 32) if kid in (KID_WCOL, KID_MOVE, KID_LIN, KID_CUB) else 1
+            # the row-rolling kernel (plan id 6) takes up to per_launch images in one launch, the kernels of the wide sample types (7 - 10) up to 128; every other kernel is one launch per image
+            ipl = min(n, per_launch) if kid == KID_ROLL else min(n, 128) if kid in (KID_WCOL, KID_MOVE, KID_LIN, KID_CUB) else 1
             entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc), "images_per_launch": ipl, "launches_timed": reps * ((n + ipl - 1) // ipl),
                           "us_per_image": round(us, 2), "GBs": round(algo / us / 1e3, 1),
                           "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4), "mpix_s": round(w * h / us, 1),

@@ -30,7 +30,7 @@ extern "C" hipError_t fixca_launch_cub_batch(const void *const *, void *const *,
 #include "fixca_move.h"
 
 /* a batch of images of one geometry: the row-rolling kernel takes up to ROLL_BATCH_MAX (128) per launch, the
- * kernels of the wide sample types (k_wcol, k_move, k_lin, k_cub) up to MOVE_BATCH_MAX (32), the other kernels one */
+ * kernels of the wide sample types (k_wcol, k_move, k_lin, k_cub) up to MOVE_BATCH_MAX (128), the other kernels one */
 static int launch_many(const void *const *d_src, void *const *d_dst, int n, const FixcaGeom *g, const FixcaPlan *pl,
                        hipStream_t stream, int *launches);
 

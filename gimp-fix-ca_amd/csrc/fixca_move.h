@@ -15,7 +15,11 @@
 #define MOVE_RB4 1          /* ... with 4-KiB ring rows                                                     */
 #endif
 #define MOVE_RB(nu) ((nu) == 1 ? MOVE_RB1 : (nu) == 2 ? MOVE_RB2 : MOVE_RB4)
-#define MOVE_BATCH_MAX 32   /* images per launch (fixca_batch_device): 512 bytes of kernel arguments         */
+#ifndef MOVE_BATCH_MAX
+#define MOVE_BATCH_MAX 128  /* images per launch (fixca_batch_device): 2 KiB of kernel arguments, as RollBatch.  RGBA u16
+                             * cubic 16 / 32 / 64 / 128 per launch: 52.3 / 53.0 / 53.3 / 53.4 %, u16 linear 62.6 / 63.8 / 64.3 /
+                             * 64.5 %, float cubic 58.3 / 58.6 / 59.0 (64) %: profiles/r03_sweep_r3y_batch_size.txt */
+#endif
 #define MOVE_NU_MAX  4      /* most 16-byte units a lane moves per row (ring rows of 4 KB)                  */
 #ifndef MOVE_LDS_MAX
 #define MOVE_LDS_MAX (64 * 1024)   /* most ring bytes per wave                                              */

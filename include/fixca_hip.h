@@ -78,7 +78,7 @@ FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
  * "512 images" configuration): image i is d_src[i] -> d_dst[i], all rows.  The
  * pointer arrays are host arrays of device pointers (read during the call, not kept).
  * Asynchronous on `stream`.  Launches: 8-bit samples through the row-rolling kernel take
- * up to 128 images per kernel launch, the kernels of the wider sample types (7 - 10) up to 32, every
+ * and the kernels of the wider sample types (6 - 10) take up to 128 images per kernel launch, every
  * other kernel one image per launch, all back to back on `stream`.
  *
  * Stream capture: once a geometry's tables exist (one earlier call with the same size,

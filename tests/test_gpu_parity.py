@@ -455,8 +455,8 @@ def test_ring_linear_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, 
 @pytest.mark.parametrize("nch", [3, 4])
 @pytest.mark.parametrize("interp", [1, 2])
 def test_wide_rolling_kernel_batch_launch(torch_cuda, monkeypatch, bpc, dtype, nch, interp):
-    """k_wcol / k_wcol_weights take up to 32 images of one geometry per launch (block b works on tile b % nblocks of image
-    b / nblocks): 5 and 35 different images (two launches, the second of 3) through the batch entry, every one the oracle's
+    """k_wcol / k_wcol_weights take up to 128 images of one geometry per launch (block b works on tile b % nblocks of image
+    b / nblocks): 5, 35 and 131 images (two launches, the second of 3) through the batch entry, every one the oracle's
     bytes; tiles of 9 rows too (many blocks per image, the last chunk short), an odd width."""
     torch = torch_cuda
     w, h = (363, 75) if nch == 4 else (242, 75)
@@ -470,9 +470,10 @@ def test_wide_rolling_kernel_batch_launch(torch_cuda, monkeypatch, bpc, dtype, n
     assert kid == 7, desc
     po = pyoracle.make_params(**p.as_dict())
     imgs = [_wide_image(dtype, w, h, nch, 7300 + 11 * k + sb) for k in range(35)]
+    imgs = imgs + [imgs[k % 35] for k in range(96)]                              # 131: more than one launch holds
     refs = [pyoracle.region(a, po, bpc=bpc).tobytes() for a in imgs]
     srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, nch * sb)).cuda() for a in imgs]
-    for n, th in ((5, 0), (35, 0), (5, 9)):
+    for n, th in ((5, 0), (35, 0), (131, 0), (5, 9)):
         monkeypatch.setenv("FIXCA_TH", str(th)) if th else monkeypatch.delenv("FIXCA_TH", raising=False)
         dsts = [torch.full_like(t, 0x3C) for t in srcs[:n]]
         fixca.fix_ca_batch(srcs[:n], dsts, w, h, nch * sb, bpc, p)
