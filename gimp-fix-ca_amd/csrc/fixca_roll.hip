@@ -232,8 +232,9 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) roll_issue(st);
 	constexpr int LPR = 1 + ((ROLL_BPP == 4 && ROLL_WIN > 256) ? 1 : 0);     /* loads per row (RGB8: one DMA whatever the window) */
-	const int younger = st.ld - need;
-	if (younger >= 8) roll_wait_vm<8 * LPR>();
+	const int younger = st.ld - need;          /* <= RDEPTH, and = RDEPTH except at the ring's capacity and at the end of a tile */
+	if (younger == RDEPTH && RDEPTH <= 8) roll_wait_vm<RDEPTH * LPR>();
+	else if (younger >= 8) roll_wait_vm<8 * LPR>();
 	else if (younger >= 6) roll_wait_vm<6 * LPR>();
 	else if (younger >= 4) roll_wait_vm<4 * LPR>();
 	else if (younger >= 2) roll_wait_vm<2 * LPR>();
@@ -389,6 +390,18 @@ __device__ __forceinline__ void roll_wy(cfloat_p roww, int y, f32x2 (&wy)[TAPS])
 	for (int t = 0; t < TAPS; ++t) wy[t] = f32x2{ p[2 * t], p[2 * t + 1] };
 }
 
+/* ... of NR consecutive rows: one address, constant offsets (with a separate 64-bit address per row the compiler spends
+ * four scalar instructions per row on it) */
+template <int TAPS, int NR>
+__device__ __forceinline__ void roll_wy_rows(cfloat_p roww, int y, f32x2 (&wy)[NR][TAPS])
+{
+	cfloat_p p = roww + (size_t)y * 8;
+#pragma unroll
+	for (int n = 0; n < NR; ++n)
+#pragma unroll
+		for (int t = 0; t < TAPS; ++t) wy[n][t] = f32x2{ p[8 * n + 2 * t], p[8 * n + 2 * t + 1] };
+}
+
 /* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
 template <int TAPS, bool P2>
 __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 (&acc)[4], const u32x4 &idt)
@@ -479,8 +492,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 		idt[n] = roll_ring_px(st, y + n, st.my_idt);
 	}
 	f32x2 acc[NR][4], wy[NR][T];
-#pragma unroll
-	for (int n = 0; n < NR; ++n) roll_wy<TAPS>(roww, y + n, wy[n]);
+	roll_wy_rows<TAPS, NR>(roww, y, wy);
 	/* Everything this block needs from the ring is now in registers (after the wait), so the
 	 * slots of rows the NEXT block no longer touches are free already: refill them now, and the
 	 * loads travel while this block computes.  Issuing only at block boundaries would leave the
@@ -488,7 +500,11 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	{
 		const int target = min(min(bn.need4 + RDEPTH, bn.keep + st.KM), st.lastneed);
-		while (st.ld < target) roll_issue(st);
+		if (target - st.ld == NR && NR > 1) {              /* the usual case: as many rows as the block consumed */
+#pragma unroll
+			for (int n = 0; n < NR; ++n) roll_issue(st);
+		} else
+			while (st.ld < target) roll_issue(st);
 	}
 	STAMP(2);                                       /* ring reads issued and landed */
 	f32x2 rows[T - 1 + NR][4];                      /* hist rows, then the NR new rows */
