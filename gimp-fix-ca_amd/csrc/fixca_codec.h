@@ -68,6 +68,20 @@ __device__ __forceinline__ int tap_index_rt(int c0, int t, int n) { return max(0
  * coarse dyadic grid (pure shifts by halves or quarters), where such samples are common. */
 #define WIDE_FAST_EPS 1e-6
 static_assert(WIDE_FAST_EPS >= 10 * 5.6e-8, "the recheck band must stay at least 10 x the analytic bound on |x_ref - x|");
+
+/* The weight forms' last step for 16-bit samples: x (in sample units, the reference's clip(x_ref) * 65535 up to the bound
+ * above) rounded as the reference rounds (set_pixel: round(), half away from zero; x >= 0 after the clip), and whether
+ * x is within WIDE_FAST_EPS of a rounding boundary k + 1/2, i.e. whether the sample has to be recomputed operation for
+ * operation.  t = clip(x) + 1/2 is truncated (the addition is exact to 2^-37 at this magnitude, far inside the band),
+ * and x is near k + 1/2 exactly when t is near an integer: fract(t) near 0 or 1.  Five vector instructions fewer per
+ * sample than fract / compare / add-with-carry on x itself; the comparison's lane mask stays in scalar registers. */
+__device__ __forceinline__ unsigned fast_round_u16(double x, bool &near_boundary)
+{
+	const double t = __builtin_fmin(__builtin_fmax(x + 0.5, 0.5), 65535.5);
+	const double fr = __builtin_amdgcn_fract(t);
+	near_boundary = __builtin_fabs(fr - 0.5) > 0.5 - WIDE_FAST_EPS;
+	return (unsigned)t;
+}
 __device__ __forceinline__ void cr_weights(double t, double (&w)[4])
 {
 	const double t2 = t * t, t3 = t2 * t;

@@ -216,7 +216,9 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		for (int i = 0; i < NU; ++i) {
 			u32x4 v = *reinterpret_cast<const u32x4 *>(ring + bI + idoff[i]);
 			S res[NC];
-			uint32_t redo = 0;
+			unsigned long long redo_m[NC];                 /* FAST: lanes whose sample j is within the recheck band (scalar registers) */
+#pragma unroll
+			for (int j = 0; j < NC; ++j) redo_m[j] = 0;
 #pragma unroll
 			for (int j = 0; j < NC; ++j) {
 				uint32_t a0, a1;
@@ -233,11 +235,9 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 				if constexpr (FAST) {
 					const double h0 = fma(fx[i][j], (double)s10 - (double)s00, (double)s00);
 					const double h1 = fma(fx[i][j], (double)s11 - (double)s01, (double)s01);
-					double xv = fma(wy, h1 - h0, h0);
-					xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
-					const double fr = __builtin_amdgcn_fract(xv);
-					res[j] = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
-					redo |= (__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS ? 1u : 0u) << j;
+					bool near;
+					res[j] = (S)fixca_codec::fast_round_u16(fma(wy, h1 - h0, h0), near);
+					redo_m[j] = __builtin_amdgcn_ballot_w64(near);
 				} else {
 					const double p00 = C::get(s00), p10 = C::get(s10), p01 = C::get(s01), p11 = C::get(s11);
 					/* bilinear(), fix-ca.c:891-893, operation for operation */
@@ -247,8 +247,14 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 				}
 			}
 			if constexpr (FAST) {
-				if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0) != 0, 0)) {
+				unsigned long long any = 0;
+#pragma unroll
+				for (int j = 0; j < NC; ++j) any |= redo_m[j];
+				if (__builtin_expect(any != 0, 0)) {
 					/* a few samples per image: recomputed the reference's way from the source image */
+					uint32_t redo = 0;
+#pragma unroll
+					for (int j = 0; j < NC; ++j) redo |= (uint32_t)((redo_m[j] >> lane) & 1ull) << j;
 					while (redo) {
 						const int q = __builtin_ctz(redo);
 						redo &= redo - 1;

@@ -474,22 +474,24 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				}
 				y0prev[0] = y0[0]; y0prev[1] = y0[1];
 				if constexpr (FAST) {
-					uint32_t redo = 0;                          /* bit 2 * c + j: recompute that sample */
+					unsigned long long redo_m[4];               /* [2 * c + j]: lanes that must recompute that sample (scalar registers) */
 #pragma unroll
 					for (int c = 0; c < 2; ++c) {
 						double wy[4];
 						cr_weights(sfy[k][c], wy);
 #pragma unroll
 						for (int j = 0; j < 2; ++j) {
-							double xv = fma(wy[3], hh[c][j][3], fma(wy[2], hh[c][j][2], fma(wy[1], hh[c][j][1], wy[0] * hh[c][j][0])));
-							xv = __builtin_fmin(__builtin_fmax(xv, 0.0), 65535.0);
-							const double fr = __builtin_amdgcn_fract(xv);
-							outv[c][j] = (S)((uint32_t)xv + (fr >= 0.5 ? 1u : 0u));
-							redo |= (__builtin_fabs(fr - 0.5) < WIDE_FAST_EPS ? 1u : 0u) << (2 * c + j);
+							const double xv = fma(wy[3], hh[c][j][3], fma(wy[2], hh[c][j][2], fma(wy[1], hh[c][j][1], wy[0] * hh[c][j][0])));
+							bool near;
+							outv[c][j] = (S)fixca_codec::fast_round_u16(xv, near);
+							redo_m[2 * c + j] = __builtin_amdgcn_ballot_w64(near);
 						}
 					}
-					if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0) != 0, 0)) {
+					if (__builtin_expect((redo_m[0] | redo_m[1] | redo_m[2] | redo_m[3]) != 0, 0)) {
 						/* a few samples per image: one copy of the recomputation, the flagged samples of a lane in turn */
+						uint32_t redo = 0;                      /* bit 2 * c + j: recompute that sample */
+#pragma unroll
+						for (int q = 0; q < 4; ++q) redo |= (uint32_t)((redo_m[q] >> lane) & 1ull) << q;
 						while (redo) {
 							const int q = __builtin_ctz(redo);
 							redo &= redo - 1;
