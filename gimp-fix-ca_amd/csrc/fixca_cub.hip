@@ -29,6 +29,7 @@
  * (plan_cub) sends doubles here always and floats for batches.
  */
 #include "fixca_device.h"
+#include "fixca_internal.h"
 #include "fixca_codec.h"
 #include "fixca_move.h"
 #include <mutex>
@@ -152,7 +153,7 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
 	(void)vo_ld;
 	int ld = keep0 - 1;
-	uint32_t so_ld = 0;
+	[[maybe_unused]] uint32_t so_ld = 0;      /* the host pass of hipcc sees no use of it */
 	auto issue = [&]() {
 		++ld;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -317,18 +318,8 @@ fixca_launch_cub_batch(const void *const *d_src, void *const *d_dst, int n_image
 	if (!fn) return hipErrorInvalidValue;
 	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + 64;
 	if (lds > MOVE_LDS_MAX + 64) return hipErrorInvalidValue;
-	static std::mutex mu;
-	static const void *done[8];
-	static int ndone = 0;
-	{
-		std::lock_guard<std::mutex> lock(mu);
-		bool seen = false;
-		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
-		if (!seen) {
-			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + 64);
-			if (ndone < 8) done[ndone++] = fn;
-		}
-	}
+	hipError_t ea = (hipError_t)fixca_dyn_lds(fn, MOVE_LDS_MAX + 64);
+	if (ea != hipSuccess) return ea;
 	MovePlan mp;
 	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.depth = pl->depth; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
 	MoveBatch imgs;

@@ -37,8 +37,8 @@ struct FixcaPlan {
 	int ring;           /* kernels 4, 6, 8: source rows in the LDS ring         */
 	int nu;             /* kernels 8, 9, 10: KiB per ring row = 16-byte units a lane moves per output row (1, 2, 4) */
 	int depth;          /* kernels 8, 9, 10: source rows kept in flight beyond the newest row in use */
-	int wide_fast;      /* kernels 7, 10, 16-bit samples, CUBIC: the weight form with exact recomputation of the
-	                       samples near a rounding boundary (fixca_wide.hip); 0 = operation for operation */
+	int wide_fast;      /* 16-bit samples, kernel 7 (CUBIC, fixca_wide.hip) and kernel 9 (LINEAR, fixca_lin.hip): the weight form with
+	                       exact recomputation of the samples near a rounding boundary; 0 = operation for operation */
 };
 
 #define FIXCA_K_EXACT   1

@@ -17,6 +17,10 @@ int  fixca_make_plan(const FixcaGeom *g, unsigned flags, FixcaPlan *pl);
  * of a GIMP session must not change the kernels' shape.  Returns dflt otherwise. */
 int  fixca_debug_env(const char *name, int dflt, int lo, int hi);
 bool fixca_debug_flag(const char *name);
+/* Dynamic LDS above the 64-KiB default needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel, and the attribute
+ * belongs to the (device, function) pair: asked once per pair, whatever device the calling thread has selected.
+ * Returns a hipError_t (as int, so that plain C++ units can include this header). */
+int  fixca_dyn_lds(const void *fn, int bytes);
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n);
 
 #endif

@@ -31,6 +31,7 @@
  * the same full-KiB nt stores as everywhere.
  */
 #include "fixca_device.h"
+#include "fixca_internal.h"
 #include "fixca_codec.h"
 #include "fixca_move.h"
 #include <mutex>
@@ -159,7 +160,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
 	(void)vo_ld;
 	int ld = keep0 - 1;
-	uint32_t so_ld = 0;
+	[[maybe_unused]] uint32_t so_ld = 0;      /* the host pass of hipcc sees no use of it */
 	auto issue = [&]() {
 		++ld;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -397,7 +398,7 @@ k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
 	(void)vo_ld;
 	int ld = keep0 - 1;
-	uint32_t so_ld = 0;
+	[[maybe_unused]] uint32_t so_ld = 0;      /* the host pass of hipcc sees no use of it */
 	auto issue = [&]() {
 		++ld;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -551,18 +552,8 @@ fixca_launch_lin_batch(const void *const *d_src, void *const *d_dst, int n_image
 	/* + a pad for RGBA (the 16-byte read of a last, partial unit), + the staging row for RGB */
 	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + (g->nch == 3 ? LIN_RGB_ROW_BYTES : 64);
 	if (lds > MOVE_LDS_MAX + LIN_RGB_ROW_BYTES) return hipErrorInvalidValue;
-	static std::mutex mu;
-	static const void *done[24];
-	static int ndone = 0;
-	{
-		std::lock_guard<std::mutex> lock(mu);
-		bool seen = false;
-		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
-		if (!seen) {
-			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + LIN_RGB_ROW_BYTES);
-			if (ndone < 24) done[ndone++] = fn;
-		}
-	}
+	hipError_t ea = (hipError_t)fixca_dyn_lds(fn, MOVE_LDS_MAX + LIN_RGB_ROW_BYTES);
+	if (ea != hipSuccess) return ea;
 	MovePlan mp;
 	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.depth = pl->depth; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
 	MoveBatch imgs;

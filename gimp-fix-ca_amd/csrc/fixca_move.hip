@@ -31,6 +31,7 @@
  * k_wcol<.., 1> / the one-thread-per-pixel kernel.
  */
 #include "fixca_device.h"
+#include "fixca_internal.h"
 #include "fixca_move.h"
 #include <mutex>
 #include <type_traits>
@@ -154,7 +155,7 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	const int lastneed = max(yl, max(map_int(yl, g.yc, H, g.s[0], g.ys[0]), map_int(yl, g.yc, H, g.s[1], g.ys[1])));
 	const int lastneed_s = __builtin_amdgcn_readfirstlane(lastneed);
 	const uint32_t dst_bytes = (uint32_t)nrows * pitch;
-	const rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + (size_t)keep0 * pitch, 0,
+	[[maybe_unused]] const rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + (size_t)keep0 * pitch, 0,
 	                                                        (uint32_t)(lastneed_s - keep0 + 1) * pitch, 0x00020000);
 	const rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)Y0 * pitch, 0, dst_bytes, 0x00020000);
 #pragma unroll
@@ -166,12 +167,12 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	const int tail_u = (nunits - 1) >> 6, tail_lane = (nunits - 1) & 63;
 
 	/* ---- the ring ------------------------------------------------------------------------------------------------------ */
-	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
+	[[maybe_unused]] const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
 	int ld = keep0 - 1;
-	uint32_t so_ld = 0;
+	[[maybe_unused]] uint32_t so_ld = 0;      /* the host pass of hipcc sees no use of it */
 	auto issue = [&]() {
 		++ld;
-		const int slot = move_slot(ld, K, kmagic);
+		[[maybe_unused]] const int slot = move_slot(ld, K, kmagic);
 #if defined(__HIP_DEVICE_COMPILE__)
 		__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(ring + slot * WINB);
 		/* the instruction offset applies to the global and to the LDS address alike: piece i is bytes 1024 i .. of the window */
@@ -357,19 +358,9 @@ fixca_launch_move_batch(const void *const *d_src, void *const *d_dst, int n_imag
 	if (!fn) return hipErrorInvalidValue;
 	const size_t lds = (size_t)pl->ring * pl->nu * 1024 + 64;      /* + a pad: the 16-byte read of a strip's last, partial unit may end past the last ring row */
 	if (lds > MOVE_LDS_MAX + 64) return hipErrorInvalidValue;
-	/* dynamic LDS above the default limit needs the attribute once per function */
-	static std::mutex mu;
-	static const void *done[32];
-	static int ndone = 0;
-	{
-		std::lock_guard<std::mutex> lock(mu);
-		bool seen = false;
-		for (int i = 0; i < ndone; ++i) seen = seen || done[i] == fn;
-		if (!seen) {
-			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, MOVE_LDS_MAX + 64);
-			if (ndone < 32) done[ndone++] = fn;
-		}
-	}
+	/* dynamic LDS above the default limit needs the attribute once per device and function */
+	hipError_t ea = (hipError_t)fixca_dyn_lds(fn, MOVE_LDS_MAX + 64);
+	if (ea != hipSuccess) return ea;
 	MovePlan mp;
 	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.depth = pl->depth; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
 	MoveBatch imgs;

@@ -192,7 +192,7 @@ template <int TAPS, bool P2>
 __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
 {
 	++st.ld;
-	const int slot = roll_slot(st, st.ld);
+	[[maybe_unused]] const int slot = roll_slot(st, st.ld);
 #if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
 #if ROLL_BPP == 4
 	__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(st.ring + slot * RING_ROW);
@@ -859,14 +859,19 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 namespace {
 /* Tables live in device memory and are read by kernels that may still be running when the next call arrives, so a
  * geometry keeps its own buffer: a small per-thread cache of entries, least recently used first out.  An entry
- * remembers its last use with an event recorded behind the kernel that read it; evicting it waits for THAT event only
- * (an interactive preview that drags a slider brings a new parameter block per call: after 8 calls every call evicts,
- * and must not pay a device-wide synchronisation for it).  An entry used inside a stream capture is pinned: the graph
- * may replay the launch at any time, so its tables are never rebuilt (fixca_release_cache() frees them). */
+ * remembers the stream of its last reader; the event that proves that reader finished is recorded LAZILY: when the
+ * entry is evicted, or when a launch on another stream reads it (the event is then recorded behind everything the old
+ * stream has been given, which covers every reader there, and the new stream waits for it).  Round 3 recorded the event
+ * behind every launch: a recorded event makes the runtime close the kernel with a release to system scope, and a
+ * launch of one image (41 us) paid about 4 us for it ("one image per launch").  Evicting waits for THAT
+ * event only (an interactive preview that drags a slider brings a new parameter block per call: after 8 calls every
+ * call evicts, and must not pay a device-wide synchronisation for it).  An entry used inside a stream capture is
+ * pinned: the graph may replay the launch at any time, so its tables are never rebuilt (fixca_release_cache() frees
+ * them). */
 struct TableEntry {
 	bool        valid = false;
 	bool        pinned = false;             /* read by a captured launch: never evicted */
-	bool        used = false;               /* last_use has been recorded at least once */
+	bool        used = false;               /* a launch on last_stream has read the tables since last_use was last recorded */
 	int         device = -1;
 	FixcaGeom   g;                          /* the fields the tables depend on (same_tables) */
 	int         oc = 0;
@@ -874,7 +879,7 @@ struct TableEntry {
 	size_t      bytes = 0;
 	RollTables  tb;
 	hipEvent_t  ready = nullptr;            /* behind the table kernel */
-	hipEvent_t  last_use = nullptr;         /* behind the last k_roll launch that read the tables */
+	hipEvent_t  last_use = nullptr;         /* recorded on last_stream when somebody needs to know that its readers are done */
 	hipStream_t last_stream = nullptr;
 	unsigned long long tick = 0;
 };
@@ -911,6 +916,29 @@ extern "C" void ROLL_NAME(fixca_roll_release_tables)(void)
 	}
 }
 
+/* Everything last_stream has been given so far (every launch that read entry t's tables among it) is finished once
+ * t->last_use is: recorded now, not per launch.  A stream handle the caller has destroyed since (its work is finished
+ * then) or one that is capturing cannot take the record: the device is drained instead (never in a steady state). */
+static hipError_t tables_close_readers(TableEntry *t, bool *recorded)
+{
+	*recorded = false;
+	if (!t->used) return hipSuccess;
+	hipError_t e;
+	if (!t->last_use) {
+		e = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming);
+		if (e != hipSuccess) return e;
+	}
+	if (!stream_is_capturing(t->last_stream) && hipEventRecord(t->last_use, t->last_stream) == hipSuccess) {
+		*recorded = true;
+	} else {
+		(void)hipGetLastError();
+		e = hipDeviceSynchronize();
+		if (e != hipSuccess) return e;
+	}
+	t->used = false;
+	return hipSuccess;
+}
+
 /* after a launch that reads entry t's tables on `stream` */
 static hipError_t tables_mark_used(TableEntry *t, hipStream_t stream)
 {
@@ -918,21 +946,21 @@ static hipError_t tables_mark_used(TableEntry *t, hipStream_t stream)
 		t->pinned = true;
 		return hipSuccess;
 	}
-	hipError_t e;
-	if (!t->last_use) {
-		e = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming);
-		if (e != hipSuccess) return e;
+	if (fixca_debug_env("FIXCA_EXP_EAGER_EVENT", 0, 0, 1)) {         /* timing experiment: round 3's record behind every launch */
+		if (!t->last_use && hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming) != hipSuccess) return hipErrorOutOfMemory;
+		(void)hipEventRecord(t->last_use, stream);
 	}
 	if (t->used && t->last_stream != stream) {
-		/* an earlier reader on another stream may still be running: the new record must not forget it */
-		if (hipEventQuery(t->last_use) != hipSuccess) {
-			(void)hipGetLastError();
+		/* readers on the other stream may still be running: this stream's later work is put behind them, so that one
+		 * record on this stream (at eviction) covers them too */
+		bool recorded = false;
+		hipError_t e = tables_close_readers(t, &recorded);
+		if (e != hipSuccess) return e;
+		if (recorded) {
 			e = hipStreamWaitEvent(stream, t->last_use, 0);
 			if (e != hipSuccess) return e;
 		}
 	}
-	e = hipEventRecord(t->last_use, stream);
-	if (e != hipSuccess) return e;
 	t->used = true;
 	t->last_stream = stream;
 	return hipSuccess;
@@ -960,7 +988,7 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 		if (!t.valid) { slot = &t; break; }
 	if (!slot) {
 		for (TableEntry &t : g_tc)
-			if (!t.pinned && (!slot || t.tick < slot->tick)) slot = &t;
+			if (!t.pinned && !(t.used && stream_is_capturing(t.last_stream)) && (!slot || t.tick < slot->tick)) slot = &t;
 	}
 	if (!slot) {
 		fixca_fail(-4, "all %d table entries of this thread are held by captured launches: fixca_release_cache() after the graphs are destroyed", TABLE_ENTRIES);
@@ -969,8 +997,11 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	TableEntry &t = *slot;
 	if (t.valid) {
 		/* eviction: the last kernel that read this entry's tables must have finished (and with it, on its stream, every
-		 * earlier one; readers on other streams were chained into last_use by tables_mark_used) */
-		if (t.used) {
+		 * earlier one; readers on other streams were chained in front of that stream by tables_mark_used) */
+		bool recorded = false;
+		e = tables_close_readers(&t, &recorded);
+		if (e != hipSuccess) return e;
+		if (recorded) {
 			e = hipEventSynchronize(t.last_use);
 			if (e != hipSuccess) return e;
 		}
@@ -1041,16 +1072,13 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 	if (e != hipSuccess) return e;
 	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	lds += (size_t)fixca_debug_env("FIXCA_EXP_LDS_PAD", 0, 0, 128 * 1024);      /* timing experiment: fewer waves per CU */
-	static std::once_flag attr_once;
-	std::call_once(attr_once, [] {
-		(void)hipFuncSetAttribute((const void *)k_roll<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_roll<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-	});
 	const bool p2 = (pl->ring & (pl->ring - 1)) == 0;
+	{
+		const void *fn = p2 ? (g->interp == 0 ? (const void *)k_roll<1, true> : g->interp == 1 ? (const void *)k_roll<2, true> : (const void *)k_roll<4, true>)
+		                    : (g->interp == 0 ? (const void *)k_roll<1, false> : g->interp == 1 ? (const void *)k_roll<2, false> : (const void *)k_roll<4, false>);
+		e = (hipError_t)fixca_dyn_lds(fn, 96 * 1024);
+		if (e != hipSuccess) return e;
+	}
 	RollSched sc;
 	roll_make_sched(g, pl, n_images, &sc);
 	const dim3 grid((unsigned)sc.pool_blocks * (unsigned)n_images);

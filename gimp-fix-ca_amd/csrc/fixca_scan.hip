@@ -36,6 +36,7 @@
  * goes to the register-window kernel or the fp64 kernel in fixca_kernels.hip.
  */
 #include "fixca_device.h"
+#include "fixca_internal.h"
 #include <mutex>
 #include <type_traits>
 
@@ -494,12 +495,9 @@ fixca_launch_scan(const void *d_src, void *d_dst, const FixcaGeom *g, const Fixc
 	const uint8_t *s = static_cast<const uint8_t *>(d_src);
 	uint8_t *d = static_cast<uint8_t *>(d_dst);
 	const size_t lds = (size_t)pl->ring * RING_ROW + 2 * VX_CH * 4;
-	static std::once_flag attr_once;
-	std::call_once(attr_once, [] {
-		(void)hipFuncSetAttribute((const void *)k_scan<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_scan<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-		(void)hipFuncSetAttribute((const void *)k_scan<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-	});
+	const void *fn = g->interp == 0 ? (const void *)k_scan<0> : g->interp == 1 ? (const void *)k_scan<2> : (const void *)k_scan<4>;
+	hipError_t ea = (hipError_t)fixca_dyn_lds(fn, 64 * 1024);
+	if (ea != hipSuccess) return ea;
 	if (g->interp == 0)      hipLaunchKernelGGL(k_scan<0>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
 	else if (g->interp == 1) hipLaunchKernelGGL(k_scan<2>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);
 	else                     hipLaunchKernelGGL(k_scan<4>, dim3(pl->nblocks), dim3(64), lds, stream, s, d, *g, *pl);

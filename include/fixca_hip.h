@@ -77,9 +77,9 @@ FIXCA_API int fixca_region_device(const void *d_src, void *d_dst,
  * A batch of independent images of one geometry and one parameter block (the
  * "512 images" configuration): image i is d_src[i] -> d_dst[i], all rows.  The
  * pointer arrays are host arrays of device pointers (read during the call, not kept).
- * Asynchronous on `stream`.  Launches: 8-bit samples through the row-rolling kernel take
- * and the kernels of the wider sample types (6 - 10) take up to 128 images per kernel launch, every
- * other kernel one image per launch, all back to back on `stream`.
+ * Asynchronous on `stream`.  Launches: the row-rolling kernel (6) and the kernels of the
+ * wider sample types (7 - 10) take up to 128 images per kernel launch, every other kernel
+ * one image per launch, all back to back on `stream`.
  *
  * Stream capture: once a geometry's tables exist (one earlier call with the same size,
  * parameters and sample format on any stream), the call makes no allocation and no
@@ -176,7 +176,8 @@ FIXCA_API int fixca_noise_device(void *d_dst, size_t nbytes, unsigned long long 
 /*
  * Runs `launches` back-to-back kernel launches over the n_pairs src/dst pairs in
  * rotation on `stream`, bracketed by HIP events recorded on that same stream, and
- * returns the mean milliseconds per launch in *ms_per_launch.
+ * returns the mean milliseconds per launch in *ms_per_launch.  Up to 32 launches of the
+ * same rotation run untimed in front (the device clocks drop during any pause).
  */
 FIXCA_API int fixca_time_launches(const void *const *d_src, void *const *d_dst, int n_pairs,
                                   int launches, int orig_width, int orig_height, int bytes,

@@ -17,7 +17,7 @@ variants are timed in rotation, `--rounds` times.  Prints per variant the per-ro
 
     python tools/ab.py --bpp 3 HEAD th21,FIXCA_TH=21 cap168@rgb_cap168 HEAD2
 """
-import argparse, ctypes, os, statistics, sys
+import argparse, ctypes, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gimp-fix-ca_amd"))
 os.environ["FIXCA_DEBUG"] = "1"
@@ -120,6 +120,7 @@ class Env:
         for k, v in self.saved.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
+host_us = {}     # what the host spends issuing one image's work (the queue is never empty when this is below the device time)
 def timed(lib, env, per):
     # short timed regions read slow (the clocks ramp up after every pause: 16 images per pass measured 3-8 points low
     # in the first variant after a comparison): at least 64 images untimed, then at least 256 timed
@@ -129,8 +130,10 @@ def timed(lib, env, per):
             one_pass(lib, per)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        t0 = time.perf_counter()
         for _ in range(reps):
             one_pass(lib, per)
+        host_us.setdefault(id(lib), {})[tuple(sorted(env.items())) + (per,)] = (time.perf_counter() - t0) * 1e6 / (reps * N)
         e1.record()
         torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * N)
@@ -179,5 +182,6 @@ for name, path, env, per in VARIANTS:
         print("%-44s (library missing: %s)" % (name, path))
         continue
     pct = [algo / us / 1e3 / 80 for us in v]
-    print("%-44s median %6.2f us %5.1f %%   rounds: %s   [%s]" % (name, statistics.median(v), statistics.median(pct), " ".join("%5.1f" % x for x in pct),
-                                                                 plan_of(lib_for(path), env, per)), flush=True)
+    hu = host_us.get(id(lib_for(path)), {}).get(tuple(sorted(env.items())) + (per,), float("nan"))
+    print("%-44s median %6.2f us %5.1f %%   rounds: %s   host %.1f us/image   [%s]" % (name, statistics.median(v), statistics.median(pct), " ".join("%5.1f" % x for x in pct),
+                                                                 hu, plan_of(lib_for(path), env, per)), flush=True)
