@@ -62,6 +62,15 @@ CONFIGS = [
     dict(name="RGBA float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-4, params=dict(PARAMS, interpolation=1), images=32),
     dict(name="RGBA double linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=-8, params=dict(PARAMS, interpolation=1), images=16),
     dict(name="RGB float linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=-4, params=dict(PARAMS, interpolation=1), images=32),
+    # the weakest kernels belong in the line too (16-bit RGB is what a 16-bit TIFF / PNG photograph is in GIMP)
+    dict(name="RGB8 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=1, params=dict(PARAMS, interpolation=1)),
+    dict(name="RGB8 none, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=1, params=dict(PARAMS, interpolation=0)),
+    dict(name="RGB u16 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=2, params=PARAMS, images=64),
+    dict(name="RGB u16 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=2, params=dict(PARAMS, interpolation=1), images=64),
+    dict(name="RGB float cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=-4, params=PARAMS, images=32),
+    dict(name="RGB u32 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=4, params=dict(PARAMS, interpolation=1), images=32),
+    dict(name="RGBA u32 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=PARAMS, images=32),
+    dict(name="RGBA u32 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=dict(PARAMS, interpolation=1), images=32),
 ]
 
 
@@ -249,8 +258,8 @@ def run_configs(torch, fixca, dev, per_launch):
                 dt = torch.float32 if bpc == -4 else torch.float64
                 md = float((dsts[0].view(dt).to(torch.float64) - exact.view(dt).to(torch.float64)).abs().max())
             # the row-rolling kernel (plan id 6) takes up to per_launch images in one launch, the kernels of the wide sample types (7 - 10) up to 128; every other kernel is one launch per image
-            ipl = min(n, per_launch) if kid == KID_ROLL else min(n, 128) if kid in (KID_WCOL, KID_MOVE, KID_LIN, KID_CUB) else 1
-            entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc), "images_per_launch": ipl, "launches_timed": reps * ((n + ipl - 1) // ipl),
+            ipl = min(n, per_launch, 128) if kid in (KID_ROLL, KID_WCOL, KID_MOVE, KID_LIN, KID_CUB) else 1
+            entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc), "images_per_launch": ipl, "launches_timed": reps * ((n + per_launch - 1) // per_launch if ipl > 1 else n),
                           "us_per_image": round(us, 2), "GBs": round(algo / us / 1e3, 1),
                           "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4), "mpix_s": round(w * h / us, 1),
                           "max_abs_diff_vs_fp64_kernel": md})
@@ -302,6 +311,8 @@ def cold_call(torch, hsrc):
         return phases
     out = np.fromfile(dst, dtype=np.uint8)[-W * H * 4:].reshape(H, W, 4)
     pinned_best, pinned_phases = run(["--pinned"], 2)
+    fast_best, fast_phases = run(["--fast-exit"], 3)           # _exit(0) once the result file is closed: no runtime teardown
+    fast_out = np.fromfile(dst, dtype=np.uint8)[-W * H * 4:].reshape(H, W, 4) if fast_best is not None else None
     for p_ in (src, dst):
         try:
             os.remove(p_)
@@ -310,9 +321,66 @@ def cold_call(torch, hsrc):
     return {"ms": round(best, 1), "result_ready_ms": phases.get("cli:image_written"),
             "what": "fixca_cli (C host layer) on a 6000x4000 RGBA PAM in tmpfs/page cache: process start, HIP init, "
             "file read, fixca_region_host, file write, exit; a fresh process each time, best of 3; phases = ms since the parent spawned it; "
-            "ms = until the parent has reaped the child (the HIP runtime's teardown is the last ~90 ms), result_ready_ms = until the result file is written",
+            "ms = until the parent has reaped the child (the HIP runtime's teardown is the last ~90 ms), result_ready_ms = until the result file is written; "
+            "ms_with_fast_exit = the same with fixca_cli --fast-exit (_exit(0) after the result file is closed)",
             "phases": phases, "with_page_locked_images_ms": None if pinned_best is None else round(pinned_best, 1),
-            "with_page_locked_images_phases": pinned_phases}, out
+            "with_page_locked_images_phases": pinned_phases,
+            "ms_with_fast_exit": None if fast_best is None else round(fast_best, 1), "fast_exit_phases": fast_phases,
+            "fast_exit_output_equal": None if fast_out is None else bool(np.array_equal(fast_out, out))}, out
+
+
+def compact_line(full):
+    """The ONE line rank 0 prints.  The driver's record keeps the fixed keys (with `roofline` whole, scalars only) and the
+    last few KB of output, so the line stays under ~6 KB: no prose, no plan strings per configuration, no second set of
+    cold-call phases (those are in gpurun_out/bench_full.json), and the figures a reader needs first sit inside `roofline`."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config", "roofline", "ok", "checks") if k in full}
+    roof = dict(full["roofline"])
+    one = full.get("single_image_launch")
+    if one:
+        roof["single_image_us"] = one["us_per_image"]
+        roof["single_image_frac"] = one["frac"]
+        line["single_image_launch"] = {k: one[k] for k in ("us_per_image", "frac", "launches", "warmup_launches", "rotated_pairs") if k in one}
+        if "parity_vs_oracle" in one:
+            line["single_image_launch"]["oracle_max_abs_diff"] = one["parity_vs_oracle"]["max_abs_diff"]
+    if "copy_kernel_GBs" in full:
+        roof["copy_frac"] = round(full["copy_kernel_GBs"] / HBM_PEAK_GBS, 4)
+    po = full.get("parity_vs_oracle")
+    if po:
+        roof["oracle_max_abs_diff"] = po["max_abs_diff"]
+        roof["oracle_differing"] = po["differing"]
+        roof["oracle_samples"] = po["samples"]
+        roof["oracle_green_alpha_equal"] = po["green_alpha_equal"]
+    pf = full.get("parity_vs_fp64_kernel")
+    if pf:
+        roof["fp64_kernel_max_abs_diff"] = pf["max_abs_diff"]
+    if "second_allocation" in full:
+        roof["second_allocation_frac"] = full["second_allocation"]["frac"]
+    cfgs = [c for c in full.get("configs", []) if "frac" in c]
+    if cfgs:
+        rgb8 = [c for c in cfgs if c["name"].startswith("RGB8 cubic")]
+        if rgb8:
+            roof["rgb8_frac"] = rgb8[0]["frac"]
+        worst = min(cfgs, key=lambda c: c["frac"])
+        roof["min_config_frac"] = worst["frac"]
+        roof["min_config"] = worst["name"].split(",")[0]
+        line["configs"] = [{"name": c["name"].replace(", lens (658,1280), 6000x4000", "").replace(", 6000x4000", ""), "us": c["us_per_image"], "frac": c["frac"],
+                            "kernel": c["kernel"], "per_launch": c["images_per_launch"], "diff_vs_fp64": c["max_abs_diff_vs_fp64_kernel"]} for c in cfgs]
+        line["configs"] += [{"name": c["name"], "error": c["error"][:80]} for c in full["configs"] if "error" in c]
+    line["roofline"] = roof
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = full["cpu_baseline"]
+    for k in ("host_entry_pcie_inclusive_mpix_s", "host_entry_pinned_pcie_inclusive_mpix_s"):
+        if k in full:
+            line[k] = full[k]
+    pv = full.get("preview_call")
+    if pv:
+        line["preview_call"] = {k: pv[k] for k in ("ms", "calls", "cpu_oracle_ms", "vs_oracle") if k in pv}
+    cc = full.get("cold_call_ms")
+    if cc:
+        line["cold_call_ms"] = {k: cc[k] for k in ("ms", "result_ready_ms", "ms_with_fast_exit", "phases", "with_page_locked_images_ms", "error") if k in cc}
+    line["full_record"] = "gpurun_out/bench_full.json"
+    return line
 
 
 def parse_args(argv=None):
@@ -368,6 +436,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
 
+    # dmabuf IPC: RCCL between processes needs it on this pool.  Set before anything touches the GPU, also when a driver
+    # started the ranks under torch.distributed.run itself (launch_ranks sets it for the ranks it starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -402,6 +473,15 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+            if dist.get_backend() != "nccl":
+                raise SystemExit("bench.py: the process group came up as %r, not nccl (RCCL)" % dist.get_backend())
+    transport = "none"
+    if world > 1:
+        if rehearse:
+            transport = "gloo, %d ranks sharing GPU 0 (FIXCA_BENCH_REHEARSE: control-flow rehearsal, not a measurement)" % world
+        else:
+            transport = "rccl %s (torch.distributed nccl backend), world %d, one rank per GPU" % (
+                ".".join(str(v) for v in torch.cuda.nccl.version()), world)
 
     # rank 0 owns the parameters; everyone else receives them over RCCL
     params = fdist.broadcast_params(fixca.make_params(**PARAMS) if rank == 0 else None, src=0, device=cdev)
@@ -480,12 +560,29 @@ def main():
     checks["within_1_lsb_of_fp64_kernel"] = worst <= 1
     checks["held_images_are_the_owned_ones"] = seeds_ok
     ok = ok and worst <= 1 and seeds_ok
+    if rehearse and os.environ.get("FIXCA_BENCH_REHEARSE_FAIL_RANK") == str(rank):
+        ok = False                    # rehearsal only: what the job does when one rank's parity check fails (tests)
+        checks["rehearsal_injected_failure"] = True
     del exact, diff
     # the oracle's verdict on the timed batch itself: image 0 (rank 0 owns it) against oracle/ on the host,
     # taken before any extra touches dsts
+    single0 = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (1) one image per launch: what fix_ca_region does for the plug-in (8 rotated pairs = 1.5 GB, so no launch finds
+        # its image in the 256-MB Infinity Cache; 32 untimed + 1000 timed launches).  Timed HERE, while the device is
+        # still busy from the timed steps: the oracle check below keeps the host busy and the GPU idle for half a second
+        batch0 = dsts[0].cpu().numpy()                        # image 0 as the timed batch left it
+        nrot = min(8, n_own)
+        one_ms = fixca.time_launches(srcs[:nrot], dsts[:nrot], 1000, W, H, C, 1, params)
+        kid1, plan1 = fixca.plan(W, H, C, 1, params)
+        extra["single_image_launch"] = {"us_per_image": round(one_ms * 1e3, 2), "launches": 1000, "warmup_launches": 32, "rotated_pairs": nrot,
+                                        "frac": round(2.0 * W * H * C / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "kernel_plan": plan1}
+        single0 = dsts[0].cpu().numpy()
     if rank == 0 and not args.no_cpu_baseline:
         ref0 = oracle_image0(PARAMS)
-        batch0 = dsts[0].cpu().numpy()
+        if single0 is None:
+            batch0 = dsts[0].cpu().numpy()
         extra["parity_vs_oracle"] = oracle_diff(np, batch0, ref0)
         checks["within_1_lsb_of_cpu_oracle"] = extra["parity_vs_oracle"]["max_abs_diff"] <= 1 and extra["parity_vs_oracle"]["green_alpha_equal"]
         ok = ok and checks["within_1_lsb_of_cpu_oracle"]
@@ -498,18 +595,11 @@ def main():
         extra["parity_vs_fp64_kernel"] = {"images_checked": [own[j] for j in checked], "max_abs_diff": worst,
                                           "max_differing_samples_per_image": differing, "samples_per_image": W * H * C}
         if world == 1 and not args.no_extras:
-            # (1) one image per launch: what fix_ca_region does for the plug-in (8 rotated pairs, 200 launches)
-            nrot = min(8, n_own)
-            one_ms = fixca.time_launches(srcs[:nrot], dsts[:nrot], 200, W, H, C, 1, params)
-            kid1, plan1 = fixca.plan(W, H, C, 1, params)
-            extra["single_image_launch"] = {"us_per_image": round(one_ms * 1e3, 2), "launches": 200, "rotated_pairs": nrot,
-                                            "frac": round(2.0 * W * H * C / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                            "kernel_plan": plan1}
-            # (2) the on-box copy yardstick over the same buffers (it overwrites dsts: keep what is compared later)
-            batch0 = dsts[0].cpu().numpy()
             if "parity_vs_oracle" in extra:              # one image per launch against the oracle too
-                extra["single_image_launch"]["parity_vs_oracle"] = oracle_diff(np, batch0, ref0)
+                extra["single_image_launch"]["parity_vs_oracle"] = oracle_diff(np, single0, ref0)
                 ok = ok and extra["single_image_launch"]["parity_vs_oracle"]["max_abs_diff"] <= 1
+            batch0 = single0
+            # (2) the on-box copy yardstick over the same buffers (it overwrites dsts)
             copy_ms = fixca.time_copy(srcs[:32], dsts[:32], 320, W * H * C)
             extra["copy_kernel_GBs"] = round(2 * W * H * C / (copy_ms * 1e-3) / 1e9, 1)
             # (3) the host entry, PCIe inclusive (never the bench value)
@@ -605,8 +695,7 @@ def main():
                        "launches_per_step": launches_per_step,
                        "parallelism": "image i -> rank i mod %d, params broadcast from rank 0, no pixel traffic" % world,
                        "images_by_rank": [o if len(o) <= 16 else o[:4] + ["..."] + o[-2:] for o in owned],
-                       "transport": "gloo, ranks sharing GPU 0 (FIXCA_BENCH_REHEARSE: control-flow rehearsal, not a measurement)" if rehearse
-                                    else ("rccl" if world > 1 else "none"),
+                       "transport": transport,
                        "kernel_plan": plan_text},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -632,7 +721,17 @@ def main():
                 out["checks"]["preview_within_1_lsb_of_cpu_oracle"] = bool(good)
                 out["ok"] = bool(out["ok"] and good)
                 ok = ok and good
-        print(json.dumps(out), flush=True)
+        line = compact_line(out)
+        try:                                   # the whole record (prose, plans, every phase) next to the line
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+        if line["ok"]:
+            print(json.dumps(line), flush=True)
+        else:                                  # a job whose check failed on any rank has no result line, only a non-zero exit
+            print("bench.py: parity check failed; the record without a result line: " + json.dumps(line), file=sys.stderr, flush=True)
 
     if world > 1:
         dist.destroy_process_group()

@@ -53,20 +53,30 @@ extern "C" const char *fixca_last_error(void) { return g_err; }
 #include <time.h>
 extern "C" void fixca_phase(const char *name)
 {
-	static int on = -1;
-	static long long t0 = 0;
-	if (on < 0) {
-		const char *e = getenv("FIXCA_PHASES");
-		on = (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
-		const char *z = getenv("FIXCA_T0_NS");
-		if (z && *z) t0 = atoll(z);
-	}
-	if (!on) return;
+	/* the prewarm thread and the calling thread may both make the first call: the settings are read once, behind the
+	 * guard of a function-local static, and the clock origin (when the parent gave none) is taken there too */
+	struct Settings {
+		bool      on;
+		long long t0;
+		Settings()
+		{
+			const char *e = getenv("FIXCA_PHASES");
+			on = e && *e && strcmp(e, "0") != 0;
+			const char *z = getenv("FIXCA_T0_NS");
+			t0 = (z && *z) ? atoll(z) : 0;
+			if (on && !t0) {
+				struct timespec ts;
+				clock_gettime(CLOCK_MONOTONIC, &ts);
+				t0 = (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+			}
+		}
+	};
+	static const Settings cfg;
+	if (!cfg.on) return;
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	const long long now = (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
-	if (!t0) t0 = now;
-	fprintf(stderr, "fixca-phase %s %.3f\n", name, (double)(now - t0) / 1e6);
+	fprintf(stderr, "fixca-phase %s %.3f\n", name, (double)(now - cfg.t0) / 1e6);
 }
 extern "C" int fixca_abi_version(void) { return 1; }
 

@@ -537,6 +537,17 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
 		for (int k = 0; k < 4; ++k) st.hist[t][k] = rows[NR + t][k];
+#ifdef ROLL_EXP_VALU
+	/* timing experiment (tools/build_variant.sh NAME -DROLL_EXP_VALU=n, never the shipped library): n more packed
+	 * FMAs per output row on four independent chains: what a heavier filter of the same data movement would cost */
+	{
+		f32x2 d[4] = { acc[0][0], acc[0][1], acc[0][2], acc[0][3] };
+#pragma unroll
+		for (int i = 0; i < ROLL_EXP_VALU * NR; ++i)
+			asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(d[i & 3]) : "v"(wy[0][0]));
+		asm volatile("" :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+	}
+#endif
 	ROLL_EXP_SINK(acc, NR);
 	STAMP(3);                                       /* filter arithmetic */
 #pragma unroll

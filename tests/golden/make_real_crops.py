@@ -1,4 +1,4 @@
-"""Cuts two lossless crops out of the reference's sample photographs
+"""Cuts three lossless crops out of the reference's sample photographs
 (/root/reference/img-fix-ca/*.jpg, decoded with PIL .convert('RGB')) and stores
 them as raw uint8 .npy next to the md5 of the CPU oracle's output for every
 interpolation mode.  The crops are DATA (decoded pixels of the reference's own
@@ -36,6 +36,9 @@ def main():
          dict(blue=6.0, red=-2.4, lens_x=58, lens_y=180)),
         ("wat_crop", "full-Wat_Pathum_Wanaram.jpg", 1800, 1200, 255, 191,
          dict(blue=1.5, red=-1.5, lens_x=127, lens_y=95, x_blue=0.5, y_red=-1.25)),
+        # 256-aligned (W % 4 == 0, W >= 256): a reference photograph that reaches the main RGB8 kernel (k_roll_rgb)
+        ("wat_crop512", "full-Wat_Pathum_Wanaram.jpg", 1688, 1104, 512, 384,
+         dict(blue=1.5, red=-1.5, lens_x=256, lens_y=192)),
     ]
     meta = []
     for name, f, x, y, w, h, params in crops:

@@ -84,6 +84,52 @@ def test_real_image_crops(torch_cuda, crop, interp):
     assert mx <= (0 if interp == 0 else TOL_LSB)
 
 
+def test_real_photograph_reaches_the_main_rgb8_kernel():
+    """wat_crop512 (512 x 384 of the reference's Wat_Pathum photograph) is 4-aligned and at least 256 wide: KERNEL_AUTO
+    plans the row-rolling kernel's RGB8 build for it in every mode, so test_real_image_crops exercises k_roll_rgb on a
+    reference image (wat_crop, 255 wide, cannot)"""
+    crop = [c for c in real_crops() if c["name"] == "wat_crop512"][0]
+    h, w, c = crop["image"].shape
+    for interp in (0, 1, 2):
+        kid, desc = fixca.plan(w, h, c, 1, fixca.make_params(interpolation=interp, **crop["params"]))
+        assert kid == 6 and "bpp=3" in desc.split(), desc
+
+
+# ---- BASELINE configs[0] at full size: the geometries of the reference's own test and sample images (SURVEY §8d config 1) ----
+
+CONFIG1 = [
+    # Wat_Pathum's size and the parameters of BASELINE configs[0] (tests/test-fix-ca.c ... interp=None)
+    ("wat-size-none", 3888, 2592, dict(blue=1.5, red=-1.5, lens_x=1944, lens_y=1296, interpolation=0)),
+    # full-branches' size with what the reference's shipped test really passes: tests/Makefile.am:18 asks for lens
+    # (658,1280), run() reads the two lens arguments through d_int32 (fix-ca.c:254-258) and gets (0,0)
+    ("branches-size-linear-lens00", 1440, 2560, dict(blue=6.0, red=-2.4, lens_x=0, lens_y=0, interpolation=1)),
+    ("branches-size-linear-lens-asked", 1440, 2560, dict(blue=6.0, red=-2.4, lens_x=658, lens_y=1280, interpolation=1)),
+    ("branches-size-cubic-lens-asked", 1440, 2560, dict(blue=6.0, red=-2.4, lens_x=658, lens_y=1280, interpolation=2)),
+]
+
+
+@pytest.mark.parametrize("case", CONFIG1, ids=lambda c: c[0])
+def test_config1_geometries_full_size_rgb8(torch_cuda, case):
+    """RGB8 noise at the full size of the reference's two sample photographs: KERNEL_AUTO must plan the main kernel's
+    RGB8 build (k_roll_rgb) and agree with the oracle (NONE: byte for byte; LINEAR / CUBIC: within 1 LSB, green
+    equal); the fp64 kernel byte for byte in every mode."""
+    name, w, h, kw = case
+    p = fixca.make_params(**kw)
+    kid, desc = fixca.plan(w, h, 3, 1, p)
+    assert kid == 6 and "bpp=3" in desc.split(), desc
+    img = synth.noise_image(0xC0F1 + w, w, h, 3)
+    ref = oracle_run(img, p, threads=8)
+    auto = gpu_run(torch_cuda, img, p, fixca.KERNEL_AUTO, fill=0x5A)
+    if kw["interpolation"] == 0:
+        assert md5(auto) == md5(ref)
+    else:
+        mx, n = diff_stats(auto, ref)
+        assert mx <= TOL_LSB and n <= 0.02 * ref.size
+        assert np.array_equal(auto[..., 1], img[..., 1])
+    exact = gpu_run(torch_cuda, img, p, fixca.KERNEL_EXACT, fill=0xA5)
+    assert md5(exact) == md5(ref)
+
+
 # ---- shapes and edges -------------------------------------------------------------
 
 SHAPES = [(8, 1, 4), (8, 5, 3), (9, 9, 3), (11, 7, 4), (64, 40, 4), (253, 33, 3), (255, 65, 4), (256, 64, 4),
@@ -1095,6 +1141,44 @@ def test_bench_two_ranks_rehearsal(torch_cuda, repo_root):
     assert cfg["global_batch"] == 8 and cfg["images_per_gpu_per_step"] == 4
     assert cfg["images_by_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]]        # image i -> rank i mod 2
     assert out["checks"]["held_images_are_the_owned_ones"] and out["checks"]["within_1_lsb_of_fp64_kernel"]
-    assert out["parity_vs_oracle"]["max_abs_diff"] <= 1 and out["parity_vs_oracle"]["green_alpha_equal"]
+    assert out["roofline"]["oracle_max_abs_diff"] <= 1 and out["roofline"]["oracle_green_alpha_equal"]
     assert out["roofline"]["kernel"].startswith("k_roll<4")
     assert out["value"] > 0 and out["roofline"]["images_per_launch"] == 4
+    assert "gloo" in cfg["transport"] and "rehearsal" in cfg["transport"]
+    assert len(lines[0]) < 6144                             # the driver's record keeps about 8 KB of output
+
+
+def _rehearse(repo_root, args, **extra_env):
+    import subprocess
+    import sys
+    env = dict(os.environ, FIXCA_BENCH_REHEARSE="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(repo_root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_four_ranks_uneven_shares_rehearsal(torch_cuda, repo_root):
+    """10 images on 4 ranks: image i -> rank i mod 4 gives shares of 3 / 3 / 2 / 2; every rank times its own share, the
+    job's time is the slowest rank's, and the line counts all 10 images"""
+    import json
+    r = _rehearse(repo_root, ["--gpus", "4", "--global-batch", "10", "--steps", "2", "--warmup", "1", "--no-extras"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["ok"] is True
+    assert out["config"]["global_batch"] == 10
+    assert out["config"]["images_by_rank"] == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    assert out["checks"]["held_images_are_the_owned_ones"] and out["checks"]["within_1_lsb_of_fp64_kernel"]
+    # value counts the whole job: steps x 10 images x 24 Mpx over the slowest rank's wall time
+    assert abs(out["value"] - out["steps"] * 10 * 24.0 / (out["ms_per_step"] * out["steps"] * 1e-3)) <= 0.01 * out["value"]
+
+
+def test_bench_rank_failure_gives_no_result_line(torch_cuda, repo_root):
+    """one rank's parity check fails (injected in rank 1 of a 2-rank rehearsal): every rank learns it through the MIN
+    all-reduce, rank 0 prints no JSON line on stdout and the launcher exits non-zero"""
+    r = _rehearse(repo_root, ["--gpus", "2", "--global-batch", "4", "--steps", "1", "--warmup", "1", "--no-extras"],
+                  FIXCA_BENCH_REHEARSE_FAIL_RANK="1")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")], r.stdout
+    assert "parity check failed" in r.stderr
