@@ -290,6 +290,7 @@ def cold_call(torch, hsrc):
     def run(extra, reps):
         best, phases = None, None
         for _ in range(reps):                       # always a fresh child process; the later runs have the page cache and the code objects' files warm
+            time.sleep(0.5)                         # the kernel driver is still tearing the previous child down: its successor's HIP init then takes 170-190 ms instead of 55
             env = dict(os.environ, FIXCA_PHASES="1", FIXCA_T0_NS=str(time.clock_gettime_ns(time.CLOCK_MONOTONIC)))
             t = time.perf_counter()
             r = subprocess.run(base[:1] + extra + base[1:], capture_output=True, env=env)
@@ -568,11 +569,11 @@ def main():
     # taken before any extra touches dsts
     single0 = None
     if rank == 0 and world == 1 and not args.no_extras:
-        # (1) one image per launch: what fix_ca_region does for the plug-in (8 rotated pairs = 1.5 GB, so no launch finds
+        # (1) one image per launch: what fix_ca_region does for the plug-in (64 rotated pairs = 12 GB, so no launch finds
         # its image in the 256-MB Infinity Cache; 32 untimed + 1000 timed launches).  Timed HERE, while the device is
         # still busy from the timed steps: the oracle check below keeps the host busy and the GPU idle for half a second
         batch0 = dsts[0].cpu().numpy()                        # image 0 as the timed batch left it
-        nrot = min(8, n_own)
+        nrot = min(64, n_own)                                 # 64 pairs: the physical pages decide between modes 3 points apart, 8 pairs are one draw
         one_ms = fixca.time_launches(srcs[:nrot], dsts[:nrot], 1000, W, H, C, 1, params)
         kid1, plan1 = fixca.plan(W, H, C, 1, params)
         extra["single_image_launch"] = {"us_per_image": round(one_ms * 1e3, 2), "launches": 1000, "warmup_launches": 32, "rotated_pairs": nrot,
@@ -600,7 +601,7 @@ def main():
                 ok = ok and extra["single_image_launch"]["parity_vs_oracle"]["max_abs_diff"] <= 1
             batch0 = single0
             # (2) the on-box copy yardstick over the same buffers (it overwrites dsts)
-            copy_ms = fixca.time_copy(srcs[:32], dsts[:32], 320, W * H * C)
+            copy_ms = fixca.time_copy(srcs[:64], dsts[:64], 320, W * H * C)
             extra["copy_kernel_GBs"] = round(2 * W * H * C / (copy_ms * 1e-3) / 1e9, 1)
             # (3) the host entry, PCIe inclusive (never the bench value)
             hsrc = srcs[0].cpu().numpy()
@@ -666,7 +667,7 @@ def main():
                 extra["second_allocation"] = {"frac": round(2.0 * C * W * H * (n_own / len(groups2)) / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               "launches_timed": 6 * len(groups2),
                                               "what": "the timed job again on a freshly allocated image pool (not the bench value): the allocation decides between two modes"}
-                if n_own > 32:                            # the copy yardstick overwrote the first 32 results; the last one is intact
+                if n_own > 64:                            # the single-image leg and the copy yardstick overwrote the first 64 results; the last one is intact
                     checks["second_allocation_last_image_equal"] = bool(torch.equal(dst2[n_own - 1], dsts[n_own - 1]))
                     ok = ok and checks["second_allocation_last_image_equal"]
                 del src2, dst2, groups2

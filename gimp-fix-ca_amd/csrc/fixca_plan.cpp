@@ -426,6 +426,7 @@ void roll_make_sched(const FixcaGeom *g, const FixcaPlan *pl, int n_images, Roll
 	if (sc->pool_chunks < 1) sc->pool_chunks = 1;
 	sc->pool_waves = pl->nstrips * sc->pool_chunks;
 	sc->pool_blocks = (sc->pool_waves + 7) & ~7;
+	sc->edge_wb = env_int("FIXCA_EDGE_WB", n_images > 1 ? 1 : 0, 0, 1);
 }
 
 /* test hook (CPU): the schedule as numbers */

@@ -87,6 +87,10 @@ struct RollSched {
 	int pool_waves;     /* tiles per image: nstrips * pool_chunks                                 */
 	int pool_blocks;    /* workgroups per image: pool_waves rounded up to a multiple of 8          */
 	int th;             /* rows per tile                                                          */
+	int edge_wb;        /* RGBA8: lanes on a strip's partial end sectors store write-back (roll_store); 1 in launches of
+	                       several images.  A launch of one image ends with the write-back of those lines and measures
+	                       3.6 points slower with it than without (4500 wide: 53.6 against 57.2 %), a batch 3.6-4.5
+	                       points faster (62.5 -> 66.1 %, 65.6 -> 70.1 %)                      */
 };
 
 /* fixca_plan.cpp */

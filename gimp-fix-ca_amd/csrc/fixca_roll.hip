@@ -176,6 +176,10 @@ struct RollState {
 	uint32_t so_ld;             /* byte offset of source row ld + 1                             */
 	uint32_t so_st;             /* byte offset of the next output row                           */
 	uint32_t pitch;
+	uint32_t row_phase;         /* address of the strip's first byte in the next output row (only its low 6 bits count) */
+	uint32_t strip_bytes;       /* bytes of an output row this wave stores */
+	uint32_t dst_bytes;         /* size of the output descriptor: the offset that makes a store a no-op */
+	int      edge_wb;           /* RollSched::edge_wb (scalar) */
 	/* the newest T-1 horizontally filtered rows, (red, blue) of my 4 output columns */
 	f32x2    hist[T > 1 ? T - 1 : 1][4];             /* unused when T == 1 */
 };
@@ -402,6 +406,26 @@ __device__ __forceinline__ void roll_wy_rows(cfloat_p roww, int y, f32x2 (&wy)[N
 		for (int t = 0; t < TAPS; ++t) wy[n][t] = f32x2{ p[8 * n + 2 * t], p[8 * n + 2 * t + 1] };
 }
 
+/* A row store of a strip whose ends are not on 64-byte boundaries of the address space (an RGBA8 width that is not a
+ * multiple of 16 pixels, or an image that does not start on a 64-byte boundary) leaves the strip's first and last
+ * 64-byte sector half written; the neighbour strip's wave writes the other half.  Streamed (nt) to memory one half at a
+ * time, such a sector costs a read-modify-write each.  Measured with this kernel on 4496-, 4500- and 4512-pixel wide
+ * RGBA8 images: 70.5 / 65.7 / 70.4 % of the HBM peak (profiles/r04_pitch_alignment_widths.txt).  So the lanes that
+ * touch a partial end sector store write-back instead (the two halves meet in the XCD's L2 and leave it as one
+ * sector), everything else stays nt: 4500 wide 65.6 -> 70.1 % (profiles/r04_edge_sector_policy.txt).  Which rows have
+ * partial sectors is wave-uniform (a scalar branch); aligned images never take the second store.  Only in launches of
+ * several images (RollSched::edge_wb): a launch of one image ends with the write-back of those lines and loses more
+ * than the merged sectors gain.
+ * RGB8 (12 bytes per lane, 720-byte strips, almost every row unaligned) measured the same with and without
+ * (63.1 / 63.3 %): it keeps the single nt store.  ROLL_EDGE_AUX: cache policy bits of the edge stores (0 = write-back;
+ * sc0 = 1 measures the same, sc1 = 16 is four times slower). */
+#ifndef ROLL_EDGE_AUX
+#define ROLL_EDGE_AUX 0
+#endif
+#ifndef ROLL_EDGE_SPLIT
+#define ROLL_EDGE_SPLIT (ROLL_BPP == 4)
+#endif
+
 /* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
 template <int TAPS, bool P2>
 __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 (&acc)[4], const u32x4 &idt)
@@ -419,6 +443,18 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 		uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].x, 0, idt[k]);
 		out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
 	}
+#if ROLL_EDGE_SPLIT
+	/* address (mod 64) of the strip's first byte in this row and one past its last: scalar */
+	const uint32_t a0 = st.row_phase & 63u, end = a0 + st.strip_bytes;
+	st.row_phase += st.pitch;
+	if (__builtin_expect(st.edge_wb && (a0 | (end & 63u)) != 0, 0)) {
+		const uint32_t first = (uint32_t)st.lane * 16u + a0;          /* my 16 bytes, relative to the first sector's start */
+		const bool edge = (a0 != 0 && first < 64u) || ((end & 63u) != 0 && (first >> 6) == ((end - 1) >> 6));
+		const uint32_t off = st.vo_st + st.so_st, oob = st.dst_bytes;
+		__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, edge ? oob : off, 0, ROLL_ST_AUX);
+		__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, edge ? off : oob, 0, ROLL_EDGE_AUX);
+	} else
+#endif
 	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
 #else
 	/* [R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3] */
@@ -559,7 +595,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 template <int TAPS, bool P2>
 __device__ __forceinline__ void
 roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPlan &pl, const RollTables &tb,
-          int img, int strip, int Y0, int nrows)
+          int img, int strip, int Y0, int nrows, int edge_wb)
 {
 	constexpr int T = TAPS;
 	const int lane = threadIdx.x;
@@ -636,6 +672,10 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	 * check adds the row offset (the size is below 2 GB, so the sum cannot wrap) */
 	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
 	st.so_st = 0;
+	st.row_phase = (uint32_t)(uintptr_t)dst + (uint32_t)Y0 * st.pitch + (uint32_t)X0 * ROLL_BPP;      /* mod 2^32: only the low bits are used */
+	st.strip_bytes = (uint32_t)nact * 4 * ROLL_BPP;
+	st.dst_bytes = dst_bytes;
+	st.edge_wb = edge_wb;
 
 	auto run = [&](auto nw_tag) {
 		constexpr int NW = decltype(nw_tag)::value;
@@ -684,7 +724,7 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 	if (tile >= sc.pool_waves) return;
 	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
 	const int Y0 = g.y1 + chunk * sc.th;
-	roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0));
+	roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0), sc.edge_wb);
 }
 
 /* ======================================================================================

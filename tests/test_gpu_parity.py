@@ -130,6 +130,51 @@ def test_config1_geometries_full_size_rgb8(torch_cuda, case):
     assert md5(exact) == md5(ref)
 
 
+# ---- row stores whose ends are not on 64-byte boundaries (k_roll's write-back edge lanes) ----
+
+@pytest.mark.parametrize("w", [260, 500, 1000, 4500])            # RGBA8 widths that are not multiples of 16: pitch % 64 != 0
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_rgba8_unaligned_pitch_rows(torch_cuda, w, interp):
+    """an RGBA8 width that is not a multiple of 16 puts the ends of most row stores inside 64-byte sectors: the lanes
+    there store write-back, the others nt, in two instructions.  Every byte must still be written exactly once: result
+    against the oracle (NONE byte for byte), rows outside [y1, y2) untouched."""
+    torch = torch_cuda
+    h = 97
+    kw = dict(blue=1.25, red=-0.75, lens_x=w // 3, lens_y=40, interpolation=interp, x_blue=0.5, y_red=-1.5)
+    p = fixca.make_params(**kw)
+    kid, desc = fixca.plan(w, h, 4, 1, p)
+    assert kid == 6, desc
+    img = synth.noise_image(0xED6E + w, w, h, 4)
+    ref = oracle_run(img, p)
+    for y1, y2 in ((0, h), (13, 70)):
+        out = gpu_run(torch, img, p, fixca.KERNEL_AUTO, y1=y1, y2=y2, fill=0x3C)
+        mx, _ = diff_stats(out[y1:y2], ref[y1:y2])
+        assert mx <= (0 if interp == 0 else TOL_LSB)
+        assert np.array_equal(out[y1:y2, :, 1::2], img[y1:y2, :, 1::2])
+        assert (out[:y1] == 0x3C).all() and (out[y2:] == 0x3C).all()
+
+
+@pytest.mark.parametrize("shift", [16, 32, 48])
+def test_rgba8_image_not_on_a_sector_boundary(torch_cuda, shift):
+    """the result image starts 16 / 32 / 48 bytes past a 64-byte boundary (a caller's sub-allocation): the same split,
+    decided by the address, not by the width; the bytes around the image stay as they were"""
+    torch = torch_cuda
+    w, h = 512, 80
+    p = fixca.make_params(blue=1.5, red=-1.0, lens_x=200, lens_y=33, interpolation=2, y_blue=0.75)
+    img = synth.noise_image(0xBA5E + shift, w, h, 4)
+    ref = oracle_run(img, p)
+    src = torch.from_numpy(img).cuda()
+    n = w * h * 4
+    buf = torch.full((n + 256,), 0x77, dtype=torch.uint8, device="cuda")
+    assert buf.data_ptr() % 64 == 0
+    dst = buf[shift:shift + n].view(h, w, 4)
+    fixca.fix_ca_region(src, dst, w, h, 4, 1, p, 0, w, 0, h, True)
+    torch.cuda.synchronize()
+    mx, _ = diff_stats(dst.cpu().numpy(), ref)
+    assert mx <= TOL_LSB
+    assert (buf[:shift] == 0x77).all() and (buf[shift + n:] == 0x77).all()
+
+
 # ---- shapes and edges -------------------------------------------------------------
 
 SHAPES = [(8, 1, 4), (8, 5, 3), (9, 9, 3), (11, 7, 4), (64, 40, 4), (253, 33, 3), (255, 65, 4), (256, 64, 4),
