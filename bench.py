@@ -365,9 +365,10 @@ def compact_line(full):
         worst = min(cfgs, key=lambda c: c["frac"])
         roof["min_config_frac"] = worst["frac"]
         roof["min_config"] = worst["name"].split(",")[0]
-        line["configs"] = [{"name": c["name"].replace(", lens (658,1280), 6000x4000", "").replace(", 6000x4000", ""), "us": c["us_per_image"], "frac": c["frac"],
-                            "kernel": c["kernel"], "per_launch": c["images_per_launch"], "diff_vs_fp64": c["max_abs_diff_vs_fp64_kernel"]} for c in cfgs]
-        line["configs"] += [{"name": c["name"], "error": c["error"][:80]} for c in full["configs"] if "error" in c]
+        line["configs_columns"] = ["name", "us_per_image", "frac_of_8TBs", "kernel", "images_per_launch", "max_abs_diff_vs_fp64_kernel"]
+        line["configs"] = [[c["name"].replace(", lens (658,1280), 6000x4000", "").replace(", 6000x4000", ""), c["us_per_image"], c["frac"],
+                            c["kernel"], c["images_per_launch"], c["max_abs_diff_vs_fp64_kernel"]] for c in cfgs]
+        line["configs"] += [[c["name"], "error: " + c["error"][:80]] for c in full["configs"] if "error" in c]
     line["roofline"] = roof
     if "cpu_baseline" in full:
         line["cpu_baseline"] = full["cpu_baseline"]
@@ -636,7 +637,7 @@ def main():
                 extra["cold_call_ms"] = cc
             del hsrc, hdst
             # (5) the same job on a second allocation of the image pool.  Which physical pages a buffer lands on decides
-            # between two modes of this kernel about 3 points apart; `value` is this run's allocation as
+            # between two modes of this kernel about 3 points apart (profiles/NOTES.md); `value` is this run's allocation as
             # it came, the second one is context for whoever reads a 69 or a 72 in the line.
             free_b, _ = torch.cuda.mem_get_info()
             if free_b > 2.2 * src_all.numel():

@@ -178,7 +178,7 @@ extern "C" int fixca_stream_sync(void *stream)
 
 /* ---- start-up overlap ---------------------------------------------------------------------------------------------
  * A PDB call is a fresh process, and the first HIP call in it costs 56-227 ms (runtime and device initialisation,
- * DESIGN.md §4 "cold-start").  fixca_prewarm() starts that work on a background thread and returns at once, so a
+ * profiles/NOTES.md, "cold-start").  fixca_prewarm() starts that work on a background thread and returns at once, so a
  * host can call it first thing in run() and spend the time in what it has to do anyway before the pixels are ready
  * (gegl_buffer_get of the drawable; fixca_cli: reading the file).  The next entry that needs the device joins the
  * thread.  Calling it is optional, calling it twice is harmless. */

@@ -274,7 +274,7 @@ k_cub(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 			}
 			out[i] = v;
 		}
-		/* scalar offset the constant 0: the store-data hazard of DESIGN.md §4 (tests/test_host_logic.py scans for it) */
+		/* scalar offset the constant 0: the store-data hazard of profiles/NOTES.md (tests/test_host_logic.py scans for it) */
 #pragma unroll
 		for (int i = 0; i < NU; ++i)
 			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);

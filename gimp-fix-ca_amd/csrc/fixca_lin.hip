@@ -8,7 +8,7 @@
  * filtered rows in registers and so does every filter operation once; it is built for CUBIC, where that saves 3/4 of
  * the fp64 work.  Its loads sit in a register queue two rows ahead, and a wave that waits for its stores to be
  * acknowledged has nothing else in flight: with its stores sent out of range RGBA float LINEAR runs in 93 instead of
- * 174 us.  LINEAR has little arithmetic to save: one output sample is 4 conversions and 10 operations.
+ * 174 us (profiles/NOTES.md).  LINEAR has little arithmetic to save: one output sample is 4 conversions and 10 operations.
  * Recomputing both rows' horizontal interpolation for every output row (twice k_wcol's filter work, no window state)
  * costs ~56 us of fp64 issue per 6000x4000 RGBA float image against 132 us of memory time at 5.8 TB/s, and frees the
  * kernel to move data the way the mover does: source rows prefetched `depth` rows ahead by LDS-DMA (no registers, no
@@ -280,7 +280,7 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 			}
 			out[i] = v;
 		}
-		/* scalar offset the constant 0: the store-data hazard of DESIGN.md §4 (tests/test_host_logic.py scans for it) */
+		/* scalar offset the constant 0: the store-data hazard of profiles/NOTES.md (tests/test_host_logic.py scans for it) */
 #pragma unroll
 		for (int i = 0; i < NU; ++i)
 			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);
@@ -483,7 +483,7 @@ k_lin_rgb(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 			for (int d = 0; d < 4; ++d) out[i][d] = stage[4 * U + d];
 		}
 		asm volatile("" ::: "memory");
-		/* scalar offset the constant 0: the store-data hazard of DESIGN.md §4 (tests/test_host_logic.py scans for it) */
+		/* scalar offset the constant 0: the store-data hazard of profiles/NOTES.md (tests/test_host_logic.py scans for it) */
 #pragma unroll
 		for (int i = 0; i < 2; ++i)
 			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] == dst_bytes ? dst_bytes : stoff[i] + so_st, 0, 2);

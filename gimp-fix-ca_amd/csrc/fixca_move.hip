@@ -288,7 +288,7 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		}
 		/* The row offset goes into the vector offset, the scalar offset stays the constant 0: with a register there the
 		 * compiler leaves no wait state between a 16-byte store and the next write of its data registers, and on MI355X the
-		 * store then carries the next row's bytes ("a hardware hazard"; tests/test_host_logic.py scans for it) */
+		 * store then carries the next row's bytes (profiles/NOTES.md, "a hardware hazard"; tests/test_host_logic.py scans for it) */
 #pragma unroll
 		for (int j = 0; j < RB; ++j) {
 			const bool live = r + j < nrows;                /* wave-uniform */

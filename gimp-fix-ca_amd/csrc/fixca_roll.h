@@ -76,7 +76,7 @@ struct RollBatch {
  * k's last waves leave, so there is no fill/drain bubble per image.
  *
  * Round 2 tried two other schedules on top of this one and dropped both (git history: a75aaf2 ..
- * 601aab9): big static pieces plus a pool of small tiles (+4-5 points in the
+ * 601aab9; profiles/NOTES.md): big static pieces plus a pool of small tiles (+4-5 points in the
  * data-movement skeleton, +-0 in the kernel once neighbouring strips share an XCD again, -2 on
  * slow-write boxes), and persistent workgroups pulling tiles from per-XCD queues (+-0 at 32 images
  * per launch, -2 at 16). */

@@ -282,7 +282,7 @@ __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2> &st, in
  * branch per block and channel picks the instantiation whose v_cvt_f32_ubyteN carry the right dword and byte as
  * constants.  Round 2 shifted the 16 bytes down by R first (three v_alignbyte per window read) and moved the next
  * lane's dwords over with v_mov_dpp before converting: 86 VALU instructions per wave and row against RGBA8's 69,
- * which is what held RGB8 11 points below RGBA8 (DESIGN.md §4 finding 6).  Here the conversion IS the byte pick,
+ * which is what held RGB8 11 points below RGBA8 (profiles/NOTES.md, finding 6).  Here the conversion IS the byte pick,
  * and the DPP shift rides on it as for RGBA.  The sources are LDS-load results, never fresh VALU results
  * (tests/test_isa_checks.py), so the hand-written DPP forms need no wait states. */
 template <int K> __device__ __forceinline__ float own_ubyte(uint32_t v)
@@ -444,10 +444,16 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 		out[k] = __builtin_amdgcn_cvt_pk_u8_f32(acc[k].y, 2, o);
 	}
 #if ROLL_EDGE_SPLIT
-	/* address (mod 64) of the strip's first byte in this row and one past its last: scalar */
-	const uint32_t a0 = st.row_phase & 63u, end = a0 + st.strip_bytes;
-	st.row_phase += st.pitch;
-	if (__builtin_expect(st.edge_wb && (a0 | (end & 63u)) != 0, 0)) {
+	bool split = false;
+	uint32_t a0 = 0, end = 0;
+	if (__builtin_expect(st.edge_wb != 0, 0)) {
+		/* address (mod 64) of the strip's first byte in this row and one past its last: scalar */
+		a0 = st.row_phase & 63u;
+		end = a0 + st.strip_bytes;
+		st.row_phase += st.pitch;
+		split = (a0 | (end & 63u)) != 0;
+	}
+	if (__builtin_expect(split, 0)) {
 		const uint32_t first = (uint32_t)st.lane * 16u + a0;          /* my 16 bytes, relative to the first sector's start */
 		const bool edge = (a0 != 0 && first < 64u) || ((end & 63u) != 0 && (first >> 6) == ((end - 1) >> 6));
 		const uint32_t off = st.vo_st + st.so_st, oob = st.dst_bytes;
@@ -914,7 +920,7 @@ namespace {
  * entry is evicted, or when a launch on another stream reads it (the event is then recorded behind everything the old
  * stream has been given, which covers every reader there, and the new stream waits for it).  Round 3 recorded the event
  * behind every launch: a recorded event makes the runtime close the kernel with a release to system scope, and a
- * launch of one image (41 us) paid about 4 us for it ("one image per launch").  Evicting waits for THAT
+ * launch of one image (41 us) paid about 4 us for it (profiles/NOTES.md, round 4 §1).  Evicting waits for THAT
  * event only (an interactive preview that drags a slider brings a new parameter block per call: after 8 calls every
  * call evicts, and must not pay a device-wide synchronisation for it).  An entry used inside a stream capture is
  * pinned: the graph may replay the launch at any time, so its tables are never rebuilt (fixca_release_cache() frees

@@ -1,5 +1,5 @@
 /*
- * weightbound.c — the error bound k_wcol's weight form rests on (fixca_wide.hip).
+ * weightbound.c — the error bound k_wcol's weight form rests on (fixca_wide.hip, profiles/NOTES.md).
  *
  * For 16-bit samples the reference computes a CUBIC sample as cubicX(cubicY(rows)) on p = s / 65535 and
  * rounds clip(v) * 65535 (fix-ca.c:896-920, 748-761, 873-880; restated below operation for operation,

@@ -285,7 +285,7 @@ def test_wide_rolling_kernel_full_size(torch_cuda, bpc, nch, interp):
     """k_wcol against the one-thread-per-pixel kernel (itself checked against the oracle above) on BASELINE's
     6000x4000: every tile geometry of a real launch, and enough samples for rare hardware races to show
     (a 16-byte buffer store followed by an overwrite of its data register lost 36 samples of 96 million on
-    RGBA double before the stores were given a constant scalar offset)."""
+    RGBA double before the stores were given a constant scalar offset, profiles/NOTES.md)."""
     torch = torch_cuda
     w, h, sb = 6000, 4000, abs(bpc)
     p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=interp)

@@ -118,7 +118,7 @@ def test_host_cache_is_per_thread():
 
 def test_no_store_data_hazard_in_kernels(tmp_path):
     """A 16-byte buffer store must not be followed directly by a VALU write of its data registers: on MI355X the
-    overwrite reaches the store when the store's scalar offset is a register (tools/store_hazard_scan.py).
+    overwrite reaches the store when the store's scalar offset is a register (tools/store_hazard_scan.py, profiles/NOTES.md).
     Compiles the kernels that use buffer stores to assembly with the library's flags and scans them."""
     import shutil, subprocess, sys, os
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

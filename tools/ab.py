@@ -1,6 +1,6 @@
 """GPU box: A/B of library builds and tuning knobs ON ONE ALLOCATION.
 
-The kernels' speed moves by +-2.5 points with the physical pages a buffer lands on, so variants
+The kernels' speed moves by +-2.5 points with the physical pages a buffer lands on (profiles/NOTES.md), so variants
 are only comparable when they share the buffers: all libraries are loaded into this process (each has its own
 planner / table caches; they share the HIP runtime), the source and result images are allocated once, and the
 variants are timed in rotation, `--rounds` times.  Prints per variant the per-round percentages of the HBM peak
@@ -171,6 +171,9 @@ for r in range(a.rounds):
                 torch.cuda.synchronize()
                 if not torch.equal(dst[N - 1], ref):
                     print("!! %s: output differs from %s in %d bytes" % (name, name0, int((dst[N - 1] != ref).sum())))
+        # the comparison left the device idle: one untimed measurement brings the clocks back, or the next round's first
+        # variant reads 2-4 points low (seen on every first variant of round 2 before this line existed)
+        timed(lib_for(path0), env0, per0)
 algo = 2.0 * PB * W * H
 # the box's own yardstick on the same buffers: the library's 16-byte-per-lane nt copy kernel
 copy_ms = fixca.time_copy([src[i] for i in range(N)], [dst[i] for i in range(N)], max(64, 4 * N), W * H * PB)

@@ -1,5 +1,5 @@
 // skel_lib — kbench2's one-wave-per-tile skeleton as a shared library, so tools/r2_exp22.py can time it on the
-// SAME buffers as the real kernel (allocation modes).  Original header:
+// SAME buffers as the real kernel (allocation modes, profiles/NOTES.md).  Original header:
 // kbench2 — on-box skeleton study for the round-2 kernel structure (no filter arithmetic, only the
 // data movement): which tile shape / schedule / cache policy gets a batch of 6000x4000 RGBA8 images
 // through the chip fastest.  Every skeleton output is checkable (R byte from 3 rows up / 3 px left,

@@ -3,7 +3,7 @@ registers are written by a VALU instruction within the next two instructions.
 
 The compiler leaves no wait state there when the store's scalar offset is a register (it counts such a store as two
 issue cycles); on MI355X that overwrite reached the store: the last lanes of each group of 16 wrote the new value
-(k_wcol).  The kernels therefore give every such store a constant scalar offset; this scan is the check.
+(profiles/NOTES.md, k_wcol).  The kernels therefore give every such store a constant scalar offset; this scan is the check.
 
     python tools/store_hazard_scan.py file.s [...]      exit status 1 if any hit
 """
