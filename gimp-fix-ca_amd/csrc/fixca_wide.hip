@@ -173,6 +173,9 @@ __device__ __forceinline__ int tap_index(int c0, int t, int n)
 #else
 #define WIDE_OCC
 #endif
+#ifndef WIDE_WY_TABLE
+#define WIDE_WY_TABLE 1        /* 0: every lane computes the row's vertical weights itself (rounds 2-3; an A/B build option) */
+#endif
 template <typename S, int NCH, int TAPS, int Q, bool ODDW, bool FAST>
 __device__ __forceinline__ void
 wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, const WidePlan &wp, int block)
@@ -203,6 +206,11 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 	__shared__ double hbuf[2][WIDE_WIN];                  /* one source row's converted samples per channel */
 	__shared__ double row_fy[2][WIDE_TH_MAX];             /* per output row of the tile: fraction ...       */
 	__shared__ int    row_y0[2][WIDE_TH_MAX];             /* ... and floor of the source coordinate          */
+	/* FAST: the four vertical Catmull-Rom weights of every output row of the tile, per channel.  They are the same for
+	 * every lane: computed once per tile by the lane that computes the row's coordinate, instead of by all 64 lanes in
+	 * every row (32 of the 70 fp64 instructions a wave spent per row; NOTES round 4 §6).  cr_weights of the same
+	 * fraction: the same bits. */
+	__shared__ double row_wy[FAST ? 2 * WIDE_TH_MAX * 4 : 1];
 
 	const int lane = threadIdx.x;
 	const int W = g.W, H = g.H;
@@ -338,6 +346,12 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				const int y0 = (int)floor(yd);
 				row_y0[c][i] = y0;
 				row_fy[c][i] = __dsub_rn(yd, (double)y0);
+				if constexpr (FAST) {
+					double w[4];
+					cr_weights(row_fy[c][i], w);
+#pragma unroll
+					for (int t = 0; t < 4; ++t) row_wy[(c * WIDE_TH_MAX + i) * 4 + t] = w[t];
+				}
 			}
 		}
 	}
@@ -475,10 +489,17 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 				y0prev[0] = y0[0]; y0prev[1] = y0[1];
 				if constexpr (FAST) {
 					unsigned long long redo_m[4];               /* [2 * c + j]: lanes that must recompute that sample (scalar registers) */
+					const int rr = min(r, nrows - 1);           /* wave-uniform: every lane reads the same 32 bytes (an LDS broadcast) */
 #pragma unroll
 					for (int c = 0; c < 2; ++c) {
 						double wy[4];
+#if WIDE_WY_TABLE
+#pragma unroll
+						for (int t = 0; t < 4; ++t) wy[t] = row_wy[(c * WIDE_TH_MAX + rr) * 4 + t];
+#else
+						(void)rr;
 						cr_weights(sfy[k][c], wy);
+#endif
 #pragma unroll
 						for (int j = 0; j < 2; ++j) {
 							const double xv = fma(wy[3], hh[c][j][3], fma(wy[2], hh[c][j][2], fma(wy[1], hh[c][j][1], wy[0] * hh[c][j][0])));
