@@ -135,44 +135,78 @@ def test_config1_geometries_full_size_rgb8(torch_cuda, case):
 @pytest.mark.parametrize("w", [260, 500, 1000, 4500])            # RGBA8 widths that are not multiples of 16: pitch % 64 != 0
 @pytest.mark.parametrize("interp", [0, 1, 2])
 def test_rgba8_unaligned_pitch_rows(torch_cuda, w, interp):
-    """an RGBA8 width that is not a multiple of 16 puts the ends of most row stores inside 64-byte sectors: the lanes
-    there store write-back, the others nt, in two instructions.  Every byte must still be written exactly once: result
-    against the oracle (NONE byte for byte), rows outside [y1, y2) untouched."""
+    """an RGBA8 width that is not a multiple of 16 puts the ends of most row stores inside 64-byte sectors.  In a launch of
+    several images (the batch entry) the lanes there store write-back and the others nt, in two instructions; one image
+    alone keeps the single nt store.  Every byte must be written exactly once either way: results against the oracle
+    (NONE byte for byte), the bytes between and around the images and rows outside [y1, y2) untouched."""
     torch = torch_cuda
     h = 97
     kw = dict(blue=1.25, red=-0.75, lens_x=w // 3, lens_y=40, interpolation=interp, x_blue=0.5, y_red=-1.5)
     p = fixca.make_params(**kw)
     kid, desc = fixca.plan(w, h, 4, 1, p)
     assert kid == 6, desc
-    img = synth.noise_image(0xED6E + w, w, h, 4)
-    ref = oracle_run(img, p)
+    tol = 0 if interp == 0 else TOL_LSB
+    imgs = [synth.noise_image(0xED6E + w + i, w, h, 4) for i in range(3)]
+    refs = [oracle_run(a, p) for a in imgs]
+    # the batch entry: three images in one launch, each at its own odd offset inside one guarded buffer
+    n = w * h * 4
+    gap = [48, 16, 32]                                           # every image base at a different position in its sector
+    buf = torch.full((3 * (n + 64) + 256,), 0x3C, dtype=torch.uint8, device="cuda")
+    srcs = [torch.from_numpy(a).cuda() for a in imgs]
+    dsts, at = [], 0
+    for i in range(3):
+        at += gap[i]
+        dsts.append(buf[at:at + n].view(h, w, 4))
+        at += n
+    fixca.fix_ca_batch(srcs, dsts, w, h, 4, 1, p)
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    at = 0
+    for i in range(3):
+        assert (host[at:at + gap[i]] == 0x3C).all()
+        at += gap[i]
+        out = host[at:at + n].reshape(h, w, 4)
+        mx, _ = diff_stats(out, refs[i])
+        assert mx <= tol
+        assert np.array_equal(out[..., 1::2], imgs[i][..., 1::2])
+        at += n
+    assert (host[at:] == 0x3C).all()
+    # one image per launch, a row range
     for y1, y2 in ((0, h), (13, 70)):
-        out = gpu_run(torch, img, p, fixca.KERNEL_AUTO, y1=y1, y2=y2, fill=0x3C)
-        mx, _ = diff_stats(out[y1:y2], ref[y1:y2])
-        assert mx <= (0 if interp == 0 else TOL_LSB)
-        assert np.array_equal(out[y1:y2, :, 1::2], img[y1:y2, :, 1::2])
+        out = gpu_run(torch, imgs[0], p, fixca.KERNEL_AUTO, y1=y1, y2=y2, fill=0x3C)
+        mx, _ = diff_stats(out[y1:y2], refs[0][y1:y2])
+        assert mx <= tol
+        assert np.array_equal(out[y1:y2, :, 1::2], imgs[0][y1:y2, :, 1::2])
         assert (out[:y1] == 0x3C).all() and (out[y2:] == 0x3C).all()
 
 
 @pytest.mark.parametrize("shift", [16, 32, 48])
 def test_rgba8_image_not_on_a_sector_boundary(torch_cuda, shift):
-    """the result image starts 16 / 32 / 48 bytes past a 64-byte boundary (a caller's sub-allocation): the same split,
-    decided by the address, not by the width; the bytes around the image stay as they were"""
+    """the result images start 16 / 32 / 48 bytes past a 64-byte boundary (a caller's sub-allocation) although the width
+    is a multiple of 16: the split is decided by the address, not by the width; the bytes around the images stay as
+    they were (batch entry: the write-back edge lanes; single entry: the plain store)"""
     torch = torch_cuda
     w, h = 512, 80
     p = fixca.make_params(blue=1.5, red=-1.0, lens_x=200, lens_y=33, interpolation=2, y_blue=0.75)
-    img = synth.noise_image(0xBA5E + shift, w, h, 4)
-    ref = oracle_run(img, p)
-    src = torch.from_numpy(img).cuda()
+    imgs = [synth.noise_image(0xBA5E + shift + i, w, h, 4) for i in range(2)]
+    refs = [oracle_run(a, p) for a in imgs]
+    srcs = [torch.from_numpy(a).cuda() for a in imgs]
     n = w * h * 4
-    buf = torch.full((n + 256,), 0x77, dtype=torch.uint8, device="cuda")
-    assert buf.data_ptr() % 64 == 0
-    dst = buf[shift:shift + n].view(h, w, 4)
-    fixca.fix_ca_region(src, dst, w, h, 4, 1, p, 0, w, 0, h, True)
-    torch.cuda.synchronize()
-    mx, _ = diff_stats(dst.cpu().numpy(), ref)
-    assert mx <= TOL_LSB
-    assert (buf[:shift] == 0x77).all() and (buf[shift + n:] == 0x77).all()
+    for batch in (True, False):
+        buf = torch.full((2 * (n + 64) + 256,), 0x77, dtype=torch.uint8, device="cuda")
+        assert buf.data_ptr() % 64 == 0
+        dsts = [buf[shift:shift + n].view(h, w, 4), buf[n + 64 + shift:n + 64 + shift + n].view(h, w, 4)]
+        if batch:
+            fixca.fix_ca_batch(srcs, dsts, w, h, 4, 1, p)
+        else:
+            for s_, d_ in zip(srcs, dsts):
+                fixca.fix_ca_region(s_, d_, w, h, 4, 1, p, 0, w, 0, h, True)
+        torch.cuda.synchronize()
+        for d_, r_ in zip(dsts, refs):
+            mx, _ = diff_stats(d_.cpu().numpy(), r_)
+            assert mx <= TOL_LSB
+        host = buf.cpu().numpy()
+        assert (host[:shift] == 0x77).all() and (host[shift + n:n + 64 + shift] == 0x77).all() and (host[n + 64 + shift + n:] == 0x77).all()
 
 
 # ---- shapes and edges -------------------------------------------------------------
