@@ -285,8 +285,11 @@ static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int
  * every tap with weight lands on pixel i + j of the lane's 8, 0 <= j <= 4; the lane windows
  * start at most 4 px before and end at most 16 px past the 256-column ring row (the pads);
  * every column that carries weight is inside the ring row. */
+static int roll_win(const FixcaGeom *g) { return g->bpp == 3 ? ROLL_WIN_RGB : ROLL_WIN; }
+
 static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 {
+	const int WIN = roll_win(g);
 	const int back = (taps == 4) ? 1 : 0, W = g->W;
 	const int nstrips = (W + oc - 1) / oc;
 	for (int st = 0; st < nstrips; ++st) {
@@ -312,12 +315,12 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 			m[c] = mn;
 		}
 		int U0 = lo & ~ROLL_U0_MASK;
-		if (U0 > W - ROLL_WIN) U0 = W - ROLL_WIN;
-		if (hi > U0 + ROLL_WIN - 1) return false;
+		if (U0 > W - WIN) U0 = W - WIN;
+		if (hi > U0 + WIN - 1) return false;
 		const int nact = (xe - X0) >> 2;                /* producing lanes; lane `nact` is read as a neighbour */
 		for (int c = 0; c < 2; ++c) {
 			const int P = X0 + m[c] - U0;
-			if (P < -4 || P + 4 * nact + 4 > ROLL_WIN + 16) return false;
+			if (P < -4 || P + 4 * nact + 4 > WIN + 16) return false;
 		}
 	}
 	return true;
@@ -325,7 +328,7 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 
 static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < ROLL_WIN) return false;
+	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < roll_win(g)) return false;
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that
@@ -377,7 +380,7 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		 * CUs.  A wave's time is (th + c) row times, c ~ 12 rows for its fixed cost and halo; a
 		 * row time grows with the k = ceil(waves / 256) waves sharing a CU about as
 		 * 0.27 + 0.05 k us (measured on MI355X, 6000x4000, k = 4..9). */
-		int per_cu = (160 * 1024) / (ring * ROLL_WIN * g->bpp + 512);
+		int per_cu = (160 * 1024) / (ring * roll_win(g) * g->bpp + 512);
 		if (per_cu > 7) per_cu = 7;                     /* one image alone: 7 waves per CU beat 8 and 9 at equal total rows (measured) */
 		int best_th = 0;
 		long best_cost = 0;

@@ -20,6 +20,11 @@
 #define ROLL_WIN 256
 #endif
 
+/* RGB8's window (fixca_roll_rgb.hip): a build option for experiments; a multiple of 16 pixels (whole 16-byte DMA lanes) */
+#ifndef ROLL_WIN_RGB
+#define ROLL_WIN_RGB 256
+#endif
+
 #ifndef ROLL_U0_MASK
 #define ROLL_U0_MASK 3
 #endif

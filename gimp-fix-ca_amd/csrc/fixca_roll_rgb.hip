@@ -6,4 +6,11 @@
  * chosen by a scalar branch (fixca_roll.hip, "RGB8 tap windows"); rows are stored 12 bytes per lane.
  */
 #define ROLL_BPP 3
+#include "fixca_roll.h"
+#if ROLL_WIN_RGB != ROLL_WIN
+#undef ROLL_WIN
+#define ROLL_WIN ROLL_WIN_RGB
+#undef ROLL_NEXT_FROM_LDS
+#define ROLL_NEXT_FROM_LDS 0
+#endif
 #include "fixca_roll.hip"
