@@ -393,16 +393,29 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 			if (chunks == 1) break;
 		}
 		if (flags & FIXCA_PLAN_BATCH) {
-			/* many images back to back: the GPU stays full whatever the wave count, and short
-			 * waves (4 x the rows a wave keeps alive, so the halo stays ~20 %) measure best:
-			 * 6000x4000, span 7: th 33 -> 35.2 us per image, 44 -> 36.0, 57 -> 37.4 */
-			best_th = 4 * span + 5;
-			/* RGB8: since the tap windows are picked apart by byte alignment (round 3) the kernel holds 181 registers, 8 waves
-			 * per CU, and longer tiles win (tools/ab.py --bpp 3, one allocation: th 25 62.6 %, 33 64.2, 41 65.8, 49 65.8,
-			 * 57 64.6; round 2's kernel, 12 waves per CU, peaked at th 21-25 with 65.1 %) */
-			if (g->bpp == 3) best_th = 6 * span - 1;
-			if (best_th < 24) best_th = 24;
+			/* many images back to back: the GPU stays full whatever the wave count, and short waves measure best.  A tile
+			 * is one rebuilt row plus blocks of 4, so heights are 4k + 1 (a leftover single row costs nearly a block).
+			 * CUBIC: 4 x the rows a wave keeps alive + 5, so the halo stays ~20 % (6000x4000, span 7: th 33 -> 35.2 us per
+			 * image, 44 -> 36.0, 57 -> 37.4; round 4, two boxes: 21 / 29 / 33 rows 72.4 / 72.5 / 72.5 %, 25: 71.8, 37+: 70.5).
+			 * LINEAR and NONE want them shorter (round 4, profiles/r04_batch_tile_heights.txt, two boxes: LINEAR 17 / 21 /
+			 * 25 / 33 rows 74.7 / 73.5-74.5 / 71.3-72.4 / 72.7-73.7 %, NONE 74.3 / 73.9-74.1 / 72.2-72.5 / 73.6). */
+			best_th = (taps == 4) ? 4 * span + 5 : 4 * span + 1;
+			/* RGB8 CUBIC: since the tap windows are picked apart by byte alignment (round 3) the kernel holds 181 registers, 8 waves
+			 * per CU, and longer tiles win (tools/ab.py --bpp 3, one allocation: th 25 62.6-63.0 %, 33 64.2-65.1, 37 66.0, 41
+			 * 65.8-66.3, 49 65.8, 57 64.6).  RGB8 LINEAR / NONE (165 / 157 registers) follow RGBA8: 17 / 21 / 25 / 29 rows
+			 * 67.6 / 67.9 / 66.5-66.7 / 65.4-65.5 % LINEAR, NONE 67.9 / 68.3 / 66.6-67.0 / 65.6 %. */
+			if (g->bpp == 3 && taps == 4) best_th = 6 * span - 1;
+			if (best_th < 21) best_th = 21;
 			if (best_th > 128) best_th = 128;
+			/* 25-row tiles of a 6000x4000 image were the one height that measured 1-2 points under both neighbours in
+			 * every mode: 160 chunks x 25 strips = 4000 tiles, 500 per XCD = a whole number of chunk rows, so the eight XCDs
+			 * walk through the same strips in step, 500 image rows apart.  Such a height moves on by one block. */
+			for (int tries = 0; tries < 4; ++tries) {
+				const long chunks = (rows + best_th - 1) / best_th;
+				const long per_xcd = ((chunks * pl->nstrips + 7) & ~7L) / 8;
+				if (chunks < 16 || per_xcd % pl->nstrips != 0) break;
+				best_th += 4;
+			}
 		}
 		pl->th = env_int("FIXCA_TH", best_th, 1, 4096);
 		/* k_roll addresses a wave's rows with 32-bit offsets into per-wave buffer descriptors */
