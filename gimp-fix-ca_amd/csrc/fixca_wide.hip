@@ -173,6 +173,9 @@ __device__ __forceinline__ int tap_index(int c0, int t, int n)
 #else
 #define WIDE_OCC
 #endif
+#ifndef WIDE_PAIR_READS
+#define WIDE_PAIR_READS 1      /* 0: each column's window read on its own (rounds 2-3; an A/B build option) */
+#endif
 #ifndef WIDE_WY_TABLE
 #define WIDE_WY_TABLE 1        /* 0: every lane computes the row's vertical weights itself (rounds 2-3; an A/B build option) */
 #endif
@@ -321,8 +324,36 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 	};
 	/* the horizontal filter of my two columns on the row in hbuf[c].  One wave: its LDS operations complete in order,
 	 * the reads see the writes of convert() */
+	/* Both of a lane's columns usually start their windows one column apart (no scale step between them, no clamping at an
+	 * image edge): then the two windows are T + 1 consecutive samples, read once (5 LDS reads of 8 bytes per channel and row
+	 * instead of 8 for CUBIC).  Whether that holds for every lane of the strip is decided once per tile (wave-uniform).
+	 * Counters of the 16-bit weight form before this: the CU's LDS busy 69 % of the time, 39 % of that in bank conflicts of
+	 * the 8-byte reads (lanes 16 apart share banks); NOTES round 4 §7.  It changes the compiler's register count by up to
+	 * +-20, and with it the waves per SIMD, so it is on only where it measured a win on both entries: RGB float CUBIC
+	 * (batch 46.3 -> 50.9 %, one image per launch 41.6 -> 44.2 %) and the RGBA 16-bit weight form (47.3 -> 48.6 % one image
+	 * per launch, +-0 batched).  Elsewhere (profiles/r04_wcol_pair_reads.txt): RGB u16 LINEAR +1.9 batched but -2.5 alone,
+	 * RGBA u16 LINEAR -1.6, RGB u32 CUBIC -0.9 (172 registers instead of 168: a wave per SIMD less), the RGB weight form
+	 * -2.3 (spills), RGBA float / u32 CUBIC -0.7 / +0.5, double +-0. */
+	constexpr bool PAIR = WIDE_PAIR_READS && T == 4 && ((FAST && NCH == 4) || (std::is_same<S, float>::value && NCH == 3));
+	bool pair_ok[2];
+#pragma unroll
+	for (int c = 0; c < 2; ++c) pair_ok[c] = PAIR && __all(hb[c][1] == hb[c][0] + 1) != 0;
 	auto hrow = [&](int c, double (&out)[2]) {
 		if constexpr (T > 1) {
+			if (pair_ok[c]) {
+				double q[T + 1];
+#pragma unroll
+				for (int t = 0; t < T + 1; ++t) q[t] = hb[c][0][t];
+#pragma unroll
+				for (int j = 0; j < 2; ++j) {
+					double p[T];
+#pragma unroll
+					for (int t = 0; t < T; ++t) p[t] = q[j + t];
+					if constexpr (FAST) out[j] = fma(wx[c][j][3], p[3], fma(wx[c][j][2], p[2], fma(wx[c][j][1], p[1], wx[c][j][0] * p[0])));
+					else out[j] = hfilter<T>(p, fx[c][j]);
+				}
+				return;
+			}
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
 				double p[T];
