@@ -317,7 +317,7 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 		int U0 = lo & ~ROLL_U0_MASK;
 		if (U0 > W - WIN) U0 = W - WIN;
 		if (hi > U0 + WIN - 1) return false;
-		const int nact = (xe - X0) >> 2;                /* producing lanes; lane `nact` is read as a neighbour */
+		const int nact = (xe - X0 + 3) >> 2;            /* producing lanes (the last may be partial); lane `nact` is read as a neighbour */
 		for (int c = 0; c < 2; ++c) {
 			const int P = X0 + m[c] - U0;
 			if (P < -4 || P + 4 * nact + 4 > WIN + 16) return false;
@@ -328,7 +328,9 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 
 static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	if ((g->bpp != 4 && g->bpp != 3) || (g->W & 3) || g->W < roll_win(g)) return false;
+	/* RGB8 rows must start on dwords (the LDS-DMA's alignment): W % 4 == 0.  RGBA8: any width (since round 4; a width that
+	 * is not a multiple of 4 ran on the register-window kernels at half the speed). */
+	if ((g->bpp != 4 && g->bpp != 3) || (g->bpp == 3 && (g->W & 3)) || g->W < roll_win(g)) return false;
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that

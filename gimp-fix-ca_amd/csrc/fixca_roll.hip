@@ -38,7 +38,8 @@
  * fp32 sample arithmetic on fp64 coordinates: within 1 LSB of the reference; green and alpha
  * are copied bit-exactly.
  *
- * The planner (fixca_plan.cpp, plan_roll) selects this kernel when W % 4 == 0, W >= 256, every
+ * The planner (fixca_plan.cpp, plan_roll) selects this kernel when W >= 256 (RGB8: and W % 4 == 0, so that rows start on
+ * dwords; an RGBA8 width that is not a multiple of 4 ends in a lane of 1-3 pixels), every
  * strip's union window fits 256 columns, its tap offsets drift by at most one column and the
  * rows alive at once fit the ring; everything else goes to the kernels in fixca_scan.hip /
  * fixca_kernels.hip.
@@ -180,6 +181,9 @@ struct RollState {
 	uint32_t strip_bytes;       /* bytes of an output row this wave stores */
 	uint32_t dst_bytes;         /* size of the output descriptor: the offset that makes a store a no-op */
 	int      edge_wb;           /* RollSched::edge_wb (scalar) */
+	int      part;              /* RGBA8, width not a multiple of 4: pixels (1..3) of the strip's last, partial lane; 0 = none (scalar) */
+	uint32_t vo_part;           /* ... that lane's byte offset inside an output row; past the end in every other lane */
+	bool     idt_al;            /* my_idt is a multiple of 16 bytes (always, unless the window was pushed back from the right edge of such an image) */
 	/* the newest T-1 horizontally filtered rows, (red, blue) of my 4 output columns */
 	f32x2    hist[T > 1 ? T - 1 : 1][4];             /* unused when T == 1 */
 };
@@ -254,6 +258,10 @@ template <int TAPS, bool P2>
 __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int row, uint32_t off)
 {
 #if ROLL_BPP == 4
+	if (__builtin_expect(!st.idt_al, 0)) {               /* wave-uniform; a misaligned ds_read_b128 is right but takes ~65 LDS cycles */
+		const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
+		return u32x4{ v.a, v.b, v.c, v.d };
+	}
 	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 #else
 	const RollPx3 v = *reinterpret_cast<const RollPx3 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
@@ -455,13 +463,22 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 	}
 	if (__builtin_expect(split, 0)) {
 		const uint32_t first = (uint32_t)st.lane * 16u + a0;          /* my 16 bytes, relative to the first sector's start */
-		const bool edge = (a0 != 0 && first < 64u) || ((end & 63u) != 0 && (first >> 6) == ((end - 1) >> 6));
+		const bool edge = (a0 != 0 && first < 64u) || ((end & 63u) != 0 && ((first + 15u) >> 6) >= ((end - 1) >> 6));
 		const uint32_t off = st.vo_st + st.so_st, oob = st.dst_bytes;
 		__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, edge ? oob : off, 0, ROLL_ST_AUX);
 		__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, edge ? off : oob, 0, ROLL_EDGE_AUX);
 	} else
 #endif
 	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
+	if (__builtin_expect(st.part != 0, 0)) {
+		/* the image's last 1-3 columns: one lane, as many dwords (a 16-byte store would run into the next row) */
+		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+		typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+		const uint32_t off = st.vo_part + st.so_st;
+		if (st.part == 1)      __builtin_amdgcn_raw_buffer_store_b32(out[0], st.rs_dst, off, 0, ROLL_ST_AUX);
+		else if (st.part == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{ out[0], out[1] }, st.rs_dst, off, 0, ROLL_ST_AUX);
+		else                   __builtin_amdgcn_raw_buffer_store_b96(u32x3{ out[0], out[1], out[2] }, st.rs_dst, off, 0, ROLL_ST_AUX);
+	}
 #else
 	/* [R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3] */
 	typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
@@ -647,7 +664,9 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	}
 
 	/* ---- per-lane tap weights: 10 coalesced 16-byte loads ---------------------------------- */
-	const int nact = min(oc, W - X0) >> 2;           /* lanes that produce output */
+	const int wcols = min(oc, W - X0);               /* output columns of this strip */
+	const int nact = (wcols + 3) >> 2;               /* lanes that produce output; the last one may hold 1-3 pixels (RGBA8, W % 4 != 0) */
+	const int nfull = wcols >> 2;                    /* ... of which these store 4 pixels */
 	f32x2 wx[4][5];
 	{
 		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
@@ -676,10 +695,13 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	st.my_idt = (uint32_t)((X0 - U0) + 4 * min(lane, nact - 1)) * ROLL_BPP;
 	/* a lane without output stores at the buffer's size: past the end whether or not the range
 	 * check adds the row offset (the size is below 2 GB, so the sum cannot wrap) */
-	st.vo_st = (lane < nact) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
+	st.vo_st = (lane < nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
 	st.so_st = 0;
+	st.part = (ROLL_BPP == 4) ? (wcols & 3) : 0;
+	st.vo_part = (st.part && lane == nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
+	st.idt_al = (ROLL_BPP != 4) || (((X0 - U0) & 3) == 0);
 	st.row_phase = (uint32_t)(uintptr_t)dst + (uint32_t)Y0 * st.pitch + (uint32_t)X0 * ROLL_BPP;      /* mod 2^32: only the low bits are used */
-	st.strip_bytes = (uint32_t)nact * 4 * ROLL_BPP;
+	st.strip_bytes = (uint32_t)wcols * ROLL_BPP;
 	st.dst_bytes = dst_bytes;
 	st.edge_wb = edge_wb;
 
@@ -812,7 +834,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 	}
 	const int U0 = min(lo & ~ROLL_U0_MASK, W - ROLL_WIN);
 
-	const int nact = min(oc, W - X0) >> 2;           /* lanes that produce output */
+	const int nact = (min(oc, W - X0) + 3) >> 2;     /* lanes that produce output (the last may hold 1-3 pixels: RGBA8, W % 4 != 0) */
 	const bool active = lane < nact;
 	const int xl = X0 + 4 * min(lane, nact - 1);     /* first output column of this lane */
 
@@ -824,7 +846,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 	for (int c = 0; c < 2; ++c)
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const int x = xl + i;
+			const int x = min(xl + i, W - 1);            /* a partial last lane: its outputs past the image repeat the last column's taps and are never stored */
 			if constexpr (T == 1) {
 				/* NONE: one "tap" of weight 1 on the rounded source column (fix-ca.c:799-809);
 				 * the 0/1 weights make the fp32 filter below an exact byte gather */

@@ -132,10 +132,11 @@ def test_config1_geometries_full_size_rgb8(torch_cuda, case):
 
 # ---- row stores whose ends are not on 64-byte boundaries (k_roll's write-back edge lanes) ----
 
-@pytest.mark.parametrize("w", [260, 500, 1000, 4500])            # RGBA8 widths that are not multiples of 16: pitch % 64 != 0
+@pytest.mark.parametrize("w", [257, 258, 259, 260, 481, 500, 1000, 1003, 4500, 4501])   # RGBA8 widths that are not multiples of 16 (pitch % 64 != 0), and of 4 (a last lane of 1-3 pixels)
 @pytest.mark.parametrize("interp", [0, 1, 2])
 def test_rgba8_unaligned_pitch_rows(torch_cuda, w, interp):
-    """an RGBA8 width that is not a multiple of 16 puts the ends of most row stores inside 64-byte sectors.  In a launch of
+    """An RGBA8 width that is not a multiple of 4 ends every row in a lane of 1-3 pixels, stored as that many dwords (481 =
+    2 x 240 + 1: a last strip of ONE column).  An RGBA8 width that is not a multiple of 16 puts the ends of most row stores inside 64-byte sectors.  In a launch of
     several images (the batch entry) the lanes there store write-back and the others nt, in two instructions; one image
     alone keeps the single nt store.  Every byte must be written exactly once either way: results against the oracle
     (NONE byte for byte), the bytes between and around the images and rows outside [y1, y2) untouched."""
