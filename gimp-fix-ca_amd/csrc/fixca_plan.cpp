@@ -328,9 +328,10 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
 
 static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
-	/* RGB8 rows must start on dwords (the LDS-DMA's alignment): W % 4 == 0.  RGBA8: any width (since round 4; a width that
-	 * is not a multiple of 4 ran on the register-window kernels at half the speed). */
-	if ((g->bpp != 4 && g->bpp != 3) || (g->bpp == 3 && (g->W & 3)) || g->W < roll_win(g)) return false;
+	/* any width from the window's up (since round 4; a width that is not a multiple of 4 ran on the register-window
+	 * kernels at a third of the speed).  RGB8 rows of such an image start at any byte: gfx950's buffer loads, LDS-DMA and
+	 * stores take byte addresses as they come (tools/skeletons/unaligned_probe.hip, profiles/r04_unaligned_probe.txt). */
+	if ((g->bpp != 4 && g->bpp != 3) || g->W < roll_win(g)) return false;
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that

@@ -38,8 +38,9 @@
  * fp32 sample arithmetic on fp64 coordinates: within 1 LSB of the reference; green and alpha
  * are copied bit-exactly.
  *
- * The planner (fixca_plan.cpp, plan_roll) selects this kernel when W >= 256 (RGB8: and W % 4 == 0, so that rows start on
- * dwords; an RGBA8 width that is not a multiple of 4 ends in a lane of 1-3 pixels), every
+ * The planner (fixca_plan.cpp, plan_roll) selects this kernel when W >= 256 (a width that is not a multiple of 4 ends in a
+ * lane of 1-3 pixels; RGB8 rows then start at any byte, which gfx950's buffer loads, LDS-DMA and stores take as it comes:
+ * tools/skeletons/unaligned_probe.hip), every
  * strip's union window fits 256 columns, its tap offsets drift by at most one column and the
  * rows alive at once fit the ring; everything else goes to the kernels in fixca_scan.hip /
  * fixca_kernels.hip.
@@ -181,9 +182,9 @@ struct RollState {
 	uint32_t strip_bytes;       /* bytes of an output row this wave stores */
 	uint32_t dst_bytes;         /* size of the output descriptor: the offset that makes a store a no-op */
 	int      edge_wb;           /* RollSched::edge_wb (scalar) */
-	int      part;              /* RGBA8, width not a multiple of 4: pixels (1..3) of the strip's last, partial lane; 0 = none (scalar) */
+	int      part;              /* width not a multiple of 4: pixels (1..3) of the strip's last, partial lane; 0 = none (scalar) */
 	uint32_t vo_part;           /* ... that lane's byte offset inside an output row; past the end in every other lane */
-	bool     idt_al;            /* my_idt is a multiple of 16 bytes (always, unless the window was pushed back from the right edge of such an image) */
+	bool     idt_al;            /* my_idt is a multiple of 16 bytes (RGB8: of 4) (always, unless the window was pushed back from the right edge of such an image) */
 	/* the newest T-1 horizontally filtered rows, (red, blue) of my 4 output columns */
 	f32x2    hist[T > 1 ? T - 1 : 1][4];             /* unused when T == 1 */
 };
@@ -264,6 +265,13 @@ __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int
 	}
 	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 #else
+	if (__builtin_expect(!st.idt_al, 0)) {
+		/* wave-uniform: the window was pushed back from the right edge of an image whose width is not a multiple of 4, my
+		 * 12 bytes start 1-3 bytes past a dword: the 16 bytes around them, shifted down */
+		const RollPx4 w = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~3u));
+		const uint32_t sh = off & 3u;
+		return u32x4{ __builtin_amdgcn_alignbyte(w.b, w.a, sh), __builtin_amdgcn_alignbyte(w.c, w.b, sh), __builtin_amdgcn_alignbyte(w.d, w.c, sh), 0u };
+	}
 	const RollPx3 v = *reinterpret_cast<const RollPx3 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, 0u };
 #endif
@@ -492,6 +500,16 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].x, 1, o2);
 	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].y, 3, o2);
 	__builtin_amdgcn_raw_buffer_store_b96(u32x3{ o0, o1, o2 }, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
+	if (__builtin_expect(st.part != 0, 0)) {
+		/* the image's last 1-3 columns (a width that is not a multiple of 4): one lane, 3 / 6 / 9 bytes, byte by byte
+		 * (a 12-byte store would run into the next row) */
+		const uint32_t off = st.vo_part + st.so_st;
+		const uint32_t d[3] = { o0, o1, o2 };
+#pragma unroll
+		for (int k = 0; k < 9; ++k)
+			if (k < 3 * st.part)
+				__builtin_amdgcn_raw_buffer_store_b8((unsigned char)(d[k >> 2] >> (8 * (k & 3))), st.rs_dst, off + k, 0, ROLL_ST_AUX);   /* the other lanes: off >= the descriptor's size */
+	}
 #endif
 	st.so_st += st.pitch;
 	/* stores are not counted by the fetch function's wait: see there */
@@ -697,9 +715,9 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	 * check adds the row offset (the size is below 2 GB, so the sum cannot wrap) */
 	st.vo_st = (lane < nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
 	st.so_st = 0;
-	st.part = (ROLL_BPP == 4) ? (wcols & 3) : 0;
+	st.part = wcols & 3;
 	st.vo_part = (st.part && lane == nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
-	st.idt_al = (ROLL_BPP != 4) || (((X0 - U0) & 3) == 0);
+	st.idt_al = ((X0 - U0) & 3) == 0;
 	st.row_phase = (uint32_t)(uintptr_t)dst + (uint32_t)Y0 * st.pitch + (uint32_t)X0 * ROLL_BPP;      /* mod 2^32: only the low bits are used */
 	st.strip_bytes = (uint32_t)wcols * ROLL_BPP;
 	st.dst_bytes = dst_bytes;

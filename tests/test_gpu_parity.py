@@ -210,6 +210,52 @@ def test_rgba8_image_not_on_a_sector_boundary(torch_cuda, shift):
         assert (host[:shift] == 0x77).all() and (host[shift + n:n + 64 + shift] == 0x77).all() and (host[n + 64 + shift + n:] == 0x77).all()
 
 
+@pytest.mark.parametrize("w", [257, 258, 259, 481, 1003, 4501])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_rgb8_widths_that_are_not_multiples_of_4(torch_cuda, w, interp):
+    """RGB8 rows of such an image start at any byte address and end in a lane of 1-3 pixels (3 / 6 / 9 bytes stored byte by
+    byte).  The main kernel takes them since round 4 (the LDS-DMA, the loads and the 12-byte stores of gfx950 take byte
+    addresses as they come: tools/skeletons/unaligned_probe.hip).  Batch and single entry against the oracle, guard bytes
+    between the images, rows outside [y1, y2) untouched."""
+    torch = torch_cuda
+    h = 83
+    kw = dict(blue=1.25, red=-0.75, lens_x=w // 3, lens_y=40, interpolation=interp, x_blue=0.5, y_red=-1.5)
+    p = fixca.make_params(**kw)
+    kid, desc = fixca.plan(w, h, 3, 1, p)
+    assert kid == 6 and "bpp=3" in desc.split(), desc
+    tol = 0 if interp == 0 else TOL_LSB
+    imgs = [synth.noise_image(0xA11B + w + i, w, h, 3) for i in range(3)]
+    refs = [oracle_run(a, p) for a in imgs]
+    n = w * h * 3
+    gap = [5, 1, 2]                                                # every image at another byte alignment
+    buf = torch.full((3 * (n + 8) + 64,), 0x3C, dtype=torch.uint8, device="cuda")
+    srcs = [torch.from_numpy(a).cuda() for a in imgs]
+    dsts, at = [], 0
+    for i in range(3):
+        at += gap[i]
+        dsts.append(buf[at:at + n].view(h, w, 3))
+        at += n
+    fixca.fix_ca_batch(srcs, dsts, w, h, 3, 1, p)
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    at = 0
+    for i in range(3):
+        assert (host[at:at + gap[i]] == 0x3C).all()
+        at += gap[i]
+        out = host[at:at + n].reshape(h, w, 3)
+        mx, _ = diff_stats(out, refs[i])
+        assert mx <= tol
+        assert np.array_equal(out[..., 1], imgs[i][..., 1])
+        at += n
+    assert (host[at:] == 0x3C).all()
+    for y1, y2 in ((0, h), (11, 60)):
+        out = gpu_run(torch, imgs[0], p, fixca.KERNEL_AUTO, y1=y1, y2=y2, fill=0x3C)
+        mx, _ = diff_stats(out[y1:y2], refs[0][y1:y2])
+        assert mx <= tol
+        assert np.array_equal(out[y1:y2, :, 1], imgs[0][y1:y2, :, 1])
+        assert (out[:y1] == 0x3C).all() and (out[y2:] == 0x3C).all()
+
+
 # ---- shapes and edges -------------------------------------------------------------
 
 SHAPES = [(8, 1, 4), (8, 5, 3), (9, 9, 3), (11, 7, 4), (64, 40, 4), (253, 33, 3), (255, 65, 4), (256, 64, 4),
