@@ -227,7 +227,11 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 	const int xe = min(X0 + wp.oc, W);                    /* one past my strip's last output column */
 	const int x = X0 + 2 * lane;                          /* my two output columns: x, x + 1 */
 	const bool act0 = x < xe, act1 = x + 1 < xe;
-	constexpr bool al4 = ALIGNED || !ODDW;                /* pixel pairs start on a dword (ODDW: the width is odd) */
+	/* Pixel pairs are moved as dwords.  With 6-byte pixels and an odd width (ODDW) the rows, and with them the pairs, start
+	 * on halfwords: gfx950's buffer loads and stores take such addresses as they come (tools/skeletons/unaligned_probe.hip;
+	 * rounds 2-3 moved those rows halfword by halfword: 5999-wide RGB u16 LINEAR / CUBIC 26.1 / 25.5 % against 55.0 / 41.7 %
+	 * at 6000) */
+	constexpr bool al4 = true;
 
 	const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<S *>(src), 0, (uint32_t)H * pitchB, 0x00020000);
 	const uint32_t dst_range = (uint32_t)nrows * pitchB;  /* also the offset that makes a lane's store a no-op */
@@ -649,8 +653,13 @@ wcol_tile(const S *__restrict__ src, S *__restrict__ dst, const FixcaGeom &g, co
 					store_dwords<PB / 4>(rd, o0, 0, px);
 					store_dwords<PB / 4>(rd, o1, 0, px + PB / 4);
 				} else {
-					store_halves<NCH>(rd, o0, 0, px, 0);
-					store_halves<NCH>(rd, o1, 0, px, NCH);
+					/* 6-byte pixels on halfword boundaries: the pair as one 12-byte store, the row's last pixel alone as 4 + 2 bytes */
+					static_assert(ALIGNED || PB == 6, "RGB u16 is the one format whose pixels are not whole dwords");
+					const uint32_t op = (act1 && live) ? o0 : dst_range, ol = (lone && live) ? o0 : dst_range;
+					store_dwords<3>(rd, op, 0, px);
+					store_dwords<1>(rd, ol, 0, px);
+					__builtin_amdgcn_raw_buffer_store_b16((unsigned short)px[1], rd, ol == dst_range ? dst_range : ol + 4, 0, 2);
+					(void)o1;
 				}
 			}
 		}

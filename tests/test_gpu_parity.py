@@ -523,7 +523,7 @@ MOVE_PARAMS = [
 
 @pytest.mark.parametrize("bpc,dtype", WIDE, ids=lambda v: str(v))
 @pytest.mark.parametrize("nch", [3, 4])
-@pytest.mark.parametrize("shape", [(158, 61), (362, 140), (1202, 77), (244, 300), (2050, 33)], ids=str)
+@pytest.mark.parametrize("shape", [(158, 61), (362, 140), (1202, 77), (244, 300), (2050, 33), (363, 71), (1201, 40)], ids=str)
 def test_move_kernel_bit_exact(torch_cuda, monkeypatch, bpc, dtype, nch, shape):
     """k_move (fixca_move.hip), interpolation NONE on every wide sample type: ring rows of 1, 2 and 4 KiB, strips that
     end in a partial 16-byte unit (RGB), several strips and tiles, row ranges, scale steps and shifts up to the ring's
