@@ -27,9 +27,8 @@
  *  - a launch takes up to MOVE_BATCH_MAX images of one geometry (fixca_batch_device).
  *
  * The planner (plan_move, fixca_plan.cpp) takes a geometry when every strip's window (identity columns + red and
- * blue source columns) fits a ring row; everything else stays with k_wcol<.., 1> / the one-thread-per-pixel kernel.
- * Rows need not be whole dwords (RGB u16 of odd width: they start on halfwords, which gfx950's LDS-DMA and 16-byte
- * stores take as they come; the row's last halfword is stored on its own).
+ * blue source columns) fits a ring row and rows are a whole number of dwords; everything else stays with
+ * k_wcol<.., 1> / the one-thread-per-pixel kernel.
  */
 #include "fixca_device.h"
 #include "fixca_internal.h"
@@ -98,10 +97,9 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 	const int U0 = __builtin_amdgcn_readfirstlane(lo & ~(move_col_align(PB) - 1));
 
 	/* ---- per-lane constants: where in a ring row each sample of my units comes from ------------------------------------ */
-	const int nbytes = (xe - X0) * PB;                 /* bytes of the strip's output row (a multiple of 2) */
+	const int nbytes = (xe - X0) * PB;                 /* bytes of the strip's output row (a multiple of 4) */
 	const int nunits = (nbytes + 15) >> 4;
 	const int tail_dw = (nbytes & 15) >> 2;            /* dwords of a last, partial unit (0: none)       */
-	const int tail_hw = (nbytes & 2) >> 1;             /* ... and a halfword after them: RGB u16, an odd number of columns */
 	uint32_t goff[NU][NG];                             /* byte offset in a ring row of gathered sample j */
 	uint32_t idoff[NU];                                /* RGBA: byte offset in a ring row of my unit      */
 	uint32_t stoff[NU];                                /* byte offset in an output row of my unit, or out of range */
@@ -163,7 +161,7 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 	for (int i = 0; i < NU; ++i) {
 		const int U = lane + 64 * i;
-		const bool whole = U < nunits - ((tail_dw | tail_hw) ? 1 : 0);
+		const bool whole = U < nunits - (tail_dw ? 1 : 0);
 		stoff[i] = whole ? (uint32_t)(X0 * PB + 16 * U) : dst_bytes;
 	}
 	const int tail_u = (nunits - 1) >> 6, tail_lane = (nunits - 1) & 63;
@@ -297,7 +295,7 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 			for (int i = 0; i < NU; ++i)
 				__builtin_amdgcn_raw_buffer_store_b128(out[j][i], rs_dst, live ? stoff[i] + so_st : dst_bytes, 0, 2);
-			if (tail_dw | tail_hw) {                        /* wave-uniform: a strip whose row does not end on a unit boundary */
+			if (tail_dw) {                                  /* wave-uniform: a strip whose row does not end on a unit boundary */
 #pragma unroll
 				for (int i = 0; i < NU; ++i)
 					if (i == tail_u) {
@@ -306,12 +304,6 @@ k_move(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 #pragma unroll
 						for (int d = 0; d < 3; ++d)
 							if (d < tail_dw) __builtin_amdgcn_raw_buffer_store_b32(out[j][i][d], rs_dst, mine ? o + 4 * d : dst_bytes, 0, 2);
-						if (tail_hw) {
-							uint32_t w = out[j][i][0];
-#pragma unroll
-							for (int d = 1; d < 4; ++d) w = (d == tail_dw) ? out[j][i][d] : w;
-							__builtin_amdgcn_raw_buffer_store_b16((unsigned short)w, rs_dst, mine ? o + 4 * tail_dw : dst_bytes, 0, 2);
-						}
 					}
 			}
 			so_st += pitch;

@@ -595,8 +595,11 @@ static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	if (g->interp != 0 || g->bpc == 1) return false;
 	const int W = g->W, pb = g->bpp, rows = g->y2 - g->y1;
 	const long long pitch = (long long)W * pb;
-	/* RGB u16 of odd width: rows start on halfwords, which gfx950's LDS-DMA and stores take as they come (since round 4;
-	 * before, such images went to k_wcol's one-tap instantiation: 19.1 % against 69.7 % at 6000 wide) */
+	/* RGB u16 of odd width: rows are not whole dwords.  gfx950 moves dwords at halfword addresses (round 4), but a buffer's
+	 * range check is per dword: the dword that holds a tile's last source halfword straddles the end of the tile's
+	 * descriptor and reads as 0 (tried: tools/fuzz_soak.py caught it at once), and the descriptor must not be stretched past
+	 * the image.  k_wcol's one-tap instantiation loads whole pixel pairs inside the row and has no such dword. */
+	if (pitch % 4) return false;
 	const int span = scan_row_span(g, 0);
 	const bool batch = (flags & FIXCA_PLAN_BATCH) != 0;
 	/* a strip is a whole number of 16-byte units AND of pixels: a multiple of `step` columns */
