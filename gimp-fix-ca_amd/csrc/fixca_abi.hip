@@ -176,6 +176,83 @@ extern "C" int fixca_stream_sync(void *stream)
 	return FIXCA_OK;
 }
 
+/* ---- does this device move dwords at any byte address? --------------------------------------------------------------
+ * Images whose rows are not whole dwords (RGB8 of a width that is not a multiple of 4, RGB u16 of odd width) run on the
+ * main kernels since round 4 because gfx950's buffer loads, LDS-DMA and 12 / 16-byte stores take byte addresses as they
+ * come (tools/skeletons/unaligned_probe.hip).  That is a property of the device's memory configuration, not of the ISA,
+ * so the planner asks: the first such geometry on a device runs this one-wave probe (a 4-KiB scratch, one
+ * synchronisation; the answer is cached per device) and falls back to the register-window kernels if the bytes that
+ * arrive are not the shifted ones.  No device (planning only): assumed, as fixca_plan_describe documents. */
+namespace {
+typedef __amdgpu_buffer_rsrc_t probe_rsrc_t;
+typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int probe_u32x3 __attribute__((ext_vector_type(3)));
+__global__ __launch_bounds__(64) void k_unaligned_probe(unsigned char *buf, int *verdict)
+{
+	/* buf: 4096 bytes; [0, 1024): a byte pattern written by the host; [2048, 3072): the store target, zeroed */
+	__shared__ __attribute__((aligned(16))) unsigned char lds[1024 + 16];
+	const int lane = threadIdx.x;
+	probe_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 4096, 0x00020000);
+	int bad = 0;
+#pragma unroll
+	for (int shift = 1; shift < 4; ++shift) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (lane < 48)
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, (unsigned)(shift + 16 * lane), 0, 0, 0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		__syncthreads();
+		const probe_u32x4 a = *reinterpret_cast<const probe_u32x4 *>(lds + 16 * lane);                 /* LDS-DMA from a byte address */
+		const probe_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(shift + 16 * lane), 0, 0);   /* plain load from one */
+		unsigned char pa[16], pb[16];
+		__builtin_memcpy(pa, &a, 16);
+		__builtin_memcpy(pb, &b, 16);
+		if (lane < 48)
+			for (int i = 0; i < 16; ++i) bad |= (pa[i] != buf[shift + 16 * lane + i]) | (pb[i] != buf[shift + 16 * lane + i]);
+		/* 12-byte store to a byte address, read back bytewise */
+		__builtin_amdgcn_raw_buffer_store_b96(probe_u32x3{ b.x, b.y, b.z }, rs, (unsigned)(2048 + shift + 12 * lane), 0, 0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (lane < 48)
+			for (int i = 0; i < 12; ++i) bad |= buf[2048 + shift + 12 * lane + i] != pb[i];
+		__syncthreads();
+	}
+	bad = __any(bad);
+	if (lane == 0) *verdict = bad ? 2 : 1;
+}
+}
+
+extern "C" int fixca_unaligned_ok(void)
+{
+	constexpr int MAXDEV = 16;
+	static std::mutex mu;
+	static int verdict[MAXDEV];                          /* 0 not asked, 1 faithful, 2 not */
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) {
+		(void)hipGetLastError();
+		return 1;                                        /* no device: the planner describes what a gfx950 would run */
+	}
+	if (dev < 0 || dev >= MAXDEV) return 0;
+	std::lock_guard<std::mutex> lock(mu);
+	if (verdict[dev] == 0) {
+		unsigned char host[4096];
+		for (int i = 0; i < 4096; ++i) host[i] = i < 2048 ? (unsigned char)(i * 7 + 3) : 0;
+		unsigned char *d = nullptr;
+		int *dv = nullptr, v = 2;
+		if (hipMalloc(&d, 4096 + sizeof(int)) == hipSuccess) {
+			dv = reinterpret_cast<int *>(d + 4096);
+			if (hipMemcpy(d, host, 4096, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dv, 0, sizeof(int)) == hipSuccess) {
+				hipLaunchKernelGGL(k_unaligned_probe, dim3(1), dim3(64), 0, 0, d, dv);
+				if (hipMemcpy(&v, dv, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) v = 2;
+			}
+			(void)hipFree(d);
+		}
+		(void)hipGetLastError();
+		verdict[dev] = (v == 1) ? 1 : 2;
+	}
+	return verdict[dev] == 1;
+}
+
 /* ---- start-up overlap ---------------------------------------------------------------------------------------------
  * A PDB call is a fresh process, and the first HIP call in it costs 56-227 ms (runtime and device initialisation,
  * profiles/NOTES.md, "cold-start").  fixca_prewarm() starts that work on a background thread and returns at once, so a

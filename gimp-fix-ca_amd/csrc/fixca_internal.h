@@ -21,6 +21,9 @@ bool fixca_debug_flag(const char *name);
  * belongs to the (device, function) pair: asked once per pair, whatever device the calling thread has selected.
  * Returns a hipError_t (as int, so that plain C++ units can include this header). */
 int  fixca_dyn_lds(const void *fn, int bytes);
+/* 1 when the current device moves dwords at any byte address faithfully (probed once per device, fixca_abi.hip), or when
+ * there is no device to ask */
+extern "C" int fixca_unaligned_ok(void);
 void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t n);
 
 #endif

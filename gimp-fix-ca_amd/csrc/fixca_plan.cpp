@@ -332,6 +332,7 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 * kernels at a third of the speed).  RGB8 rows of such an image start at any byte: gfx950's buffer loads, LDS-DMA and
 	 * stores take byte addresses as they come (tools/skeletons/unaligned_probe.hip, profiles/r04_unaligned_probe.txt). */
 	if ((g->bpp != 4 && g->bpp != 3) || g->W < roll_win(g)) return false;
+	if (((long long)g->W * g->bpp) % 4 != 0 && !fixca_unaligned_ok()) return false;      /* rows at byte addresses: only where the device is known to move them faithfully */
 	const int taps = (g->interp == 0) ? 1 : (g->interp == 1) ? 2 : 4;      /* NONE runs as a 1-tap filter */
 	const int span = scan_row_span(g, g->interp == 0 ? 0 : taps);
 	/* ring rows: the span + 3 rows a block of 4 keeps alive plus rows in flight.  16 when that
@@ -506,6 +507,8 @@ static bool wide_fast_ok(const FixcaGeom *g)
 
 static bool plan_wide(const FixcaGeom *g, FixcaPlan *pl)
 {
+	/* RGB u16 of odd width: k_wcol moves its pixel pairs as dwords at halfword addresses (round 4) */
+	if (((long long)g->W * g->bpp) % 4 != 0 && !fixca_unaligned_ok()) return false;
 	if (g->bpc == 1 || g->W < 2) return false;
 	/* NONE: the rolling kernel wins on 16-bit samples (6000x4000 RGBA u16 93 vs 129 us, RGB 83 vs 118); on 4- and
 	 * 8-byte samples the one-thread-per-pixel gather is faster (RGBA float 151 vs 189 us, double 315 vs 348) */

@@ -118,9 +118,11 @@ def test_planner_choices():
     k, desc = fixca.plan(6000, 4000, 3, 1, cub)                         # RGB: the same kernel compiled for 3 bytes per pixel
     assert k == 6 and "roll cubic bpp=3" in desc
     assert fixca.plan(6000, 4000, 3, 1, fixca.make_params(blue=1.5, red=-1.5, lens_x=3000, lens_y=2000))[0] == 6
-    k, desc = fixca.plan(6002, 4000, 3, 1, cub)                         # width not a multiple of 4: register-window kernel
+    k, desc = fixca.plan(6002, 4000, 3, 1, cub)                         # width not a multiple of 4: the main kernel since round 4 (rows at byte addresses)
+    assert k == 6 and "roll cubic bpp=3" in desc
+    assert fixca.plan(257, 193, 4, 1, cub)[0] == 6                      # ... RGBA8 too (a last lane of one pixel)
+    k, desc = fixca.plan(255, 193, 4, 1, cub)                           # narrower than the 256-column window: register-window kernel
     assert k == 3 and "fast-interp cubic" in desc
-    assert fixca.plan(257, 193, 4, 1, cub)[0] == 3                      # width not a multiple of 4
     assert fixca.plan(6000, 4000, 4, 1, cub, kernel=fixca.KERNEL_EXACT)[0] == 1
     assert fixca.plan(6, 6, 3, 1, fixca.make_params(lens_x=3, lens_y=3, interpolation=1))[0] == 1   # too narrow
     with pytest.raises(fixca.FixCaError):
