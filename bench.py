@@ -186,7 +186,8 @@ def kernel_name(kid, plan_text):
         taps = {"none": 1, "linear": 2, "cubic": 4}[words[1]]
         ring = int([w for w in words if w.startswith("ring=")][0][5:])
         rgb = "bpp=3" in words
-        return "k_roll%s<%d,%s>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false")
+        # the third template argument: the instantiation for widths that are not multiples of 4 (never the bench's images)
+        return "k_roll%s<%d,%s,false>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false")
     return {"exact-fp64": "k_exact/k_wide", "fast-none": "k_none", "fast-interp": "k_interp", "scan": "k_scan", "scanw": "k_scanw",
             "wide-roll-fp64": "k_wcol", "move-none": "k_move", "ring-linear-fp64": "k_lin", "ring-cubic-fp64": "k_cub"}.get(words[0], words[0])
 

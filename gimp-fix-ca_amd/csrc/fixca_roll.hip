@@ -153,7 +153,7 @@ __device__ __forceinline__ float next_lane_ubyte2(uint32_t v)
 #define ROLL_EXP_END(st, dst, lane, gen) do { } while (0)
 #endif
 
-template <int TAPS, bool P2>          /* P2: the ring has a power-of-two number of rows */
+template <int TAPS, bool P2, bool ODD>  /* P2: the ring has a power-of-two number of rows; ODD: see roll_tile */
 struct RollState {
 	ROLL_EXP_FIELDS
 	static constexpr int T = TAPS;
@@ -190,15 +190,15 @@ struct RollState {
 };
 
 /* ring slot of source row `row` (row >= 0): row mod K */
-template <int TAPS, bool P2>
-__device__ __forceinline__ int roll_slot(const RollState<TAPS, P2> &st, int row)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ int roll_slot(const RollState<TAPS, P2, ODD> &st, int row)
 {
 	if constexpr (P2) return row & st.KM;
 	else return row - (st.KM + 1) * (int)__umulhi((uint32_t)row, st.kmagic);
 }
 
-template <int TAPS, bool P2>
-__device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ void roll_issue(RollState<TAPS, P2, ODD> &st)
 {
 	++st.ld;
 	[[maybe_unused]] const int slot = roll_slot(st, st.ld);
@@ -235,8 +235,8 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2> &st)
  * rows' loads are younger than the one needed, and "at most ld - need operations outstanding" implies "at most
  * ld - need loads outstanding", which implies the needed row is in LDS.  Stores in flight make
  * the wait stricter, never wrong. */
-template <int TAPS, bool P2>
-__device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, int need)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ void roll_fetch(RollState<TAPS, P2, ODD> &st, int keep, int need)
 {
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
 	while (st.ld < target) roll_issue(st);
@@ -255,22 +255,26 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2> &st, int keep, in
  * (RGBA) or 12 bytes at a 4-byte aligned offset (RGB; .w unused) */
 struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(4))) RollPx3 { uint32_t a, b, c; };
-template <int TAPS, bool P2>
-__device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int row, uint32_t off)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2, ODD> &st, int row, uint32_t off)
 {
 #if ROLL_BPP == 4
-	if (__builtin_expect(!st.idt_al, 0)) {               /* wave-uniform; a misaligned ds_read_b128 is right but takes ~65 LDS cycles */
-		const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
-		return u32x4{ v.a, v.b, v.c, v.d };
+	if constexpr (ODD) {
+		if (!st.idt_al) {                                /* wave-uniform; a misaligned ds_read_b128 is right but takes ~65 LDS cycles */
+			const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
+			return u32x4{ v.a, v.b, v.c, v.d };
+		}
 	}
 	return *reinterpret_cast<const u32x4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 #else
-	if (__builtin_expect(!st.idt_al, 0)) {
-		/* wave-uniform: the window was pushed back from the right edge of an image whose width is not a multiple of 4, my
-		 * 12 bytes start 1-3 bytes past a dword: the 16 bytes around them, shifted down */
-		const RollPx4 w = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~3u));
-		const uint32_t sh = off & 3u;
-		return u32x4{ __builtin_amdgcn_alignbyte(w.b, w.a, sh), __builtin_amdgcn_alignbyte(w.c, w.b, sh), __builtin_amdgcn_alignbyte(w.d, w.c, sh), 0u };
+	if constexpr (ODD) {
+		if (!st.idt_al) {
+			/* wave-uniform: the window was pushed back from the right edge of an image whose width is not a multiple of 4, my
+			 * 12 bytes start 1-3 bytes past a dword: the 16 bytes around them, shifted down */
+			const RollPx4 w = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + (off & ~3u));
+			const uint32_t sh = off & 3u;
+			return u32x4{ __builtin_amdgcn_alignbyte(w.b, w.a, sh), __builtin_amdgcn_alignbyte(w.c, w.b, sh), __builtin_amdgcn_alignbyte(w.d, w.c, sh), 0u };
+		}
 	}
 	const RollPx3 v = *reinterpret_cast<const RollPx3 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, 0u };
@@ -283,8 +287,8 @@ __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2> &st, int
  * the access is left to the compiler as 4-byte aligned: two ds_read2_b32.
  * RGB: 12 bytes at ANY byte address (3 bytes per pixel): the 16 bytes around them are read from the dword
  * boundary below (st.tap is that boundary); the bytes are picked out where they are converted. */
-template <int TAPS, bool P2>
-__device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2> &st, int row, int off)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2, ODD> &st, int row, int off)
 {
 	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
 	return u32x4{ v.a, v.b, v.c, v.d };
@@ -346,8 +350,8 @@ __device__ __forceinline__ void rgb_cvt(int r, const u32x4 (&p)[NR], f32x2 (&tp)
 /* the 8 (NP used) pixels of the windows of NR source rows per channel, as (red, blue) floats.
  * pr / pb: my 4 pixels; with the 272-column window every lane has also read the next 4 (nr / nb),
  * with the 256-column window they come from lane L + 1 over DPP. */
-template <int TAPS, bool P2, int NR, int NP>
-__device__ __forceinline__ void roll_px8(const RollState<TAPS, P2> &st, const u32x4 (&pr)[NR], const u32x4 (&pb)[NR],
+template <int TAPS, bool P2, bool ODD, int NR, int NP>
+__device__ __forceinline__ void roll_px8(const RollState<TAPS, P2, ODD> &st, const u32x4 (&pr)[NR], const u32x4 (&pb)[NR],
                                          const u32x4 (&nr)[NR], const u32x4 (&nb)[NR], f32x2 (&tp)[NR][NP])
 {
 #if ROLL_BPP == 4
@@ -372,8 +376,8 @@ __device__ __forceinline__ void roll_px8(const RollState<TAPS, P2> &st, const u3
 }
 
 /* the pixels after my 4-pixel tap window (272-column window only; a dummy otherwise) */
-template <int TAPS, bool P2>
-__device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2> &st, int row, int off)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2, ODD> &st, int row, int off)
 {
 #if ROLL_NEXT_FROM_LDS
 	return roll_ring_win(st, row, off + 4 * ROLL_BPP);
@@ -384,14 +388,14 @@ __device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2> &st, i
 
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
  * h[i] = sum_t wx[i][t] * px8[i + t] for my 4 output columns */
-template <int TAPS, bool P2, int NW>
-__device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5],
+template <int TAPS, bool P2, bool ODD, int NW>
+__device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5],
                                           int rowR, int rowB, f32x2 (&h)[4])
 {
 	const u32x4 pr[1] = { roll_ring_win(st, rowR, st.tap[0]) }, nr[1] = { roll_ring_next(st, rowR, st.tap[0]) };
 	const u32x4 pb[1] = { roll_ring_win(st, rowB, st.tap[1]) }, nb[1] = { roll_ring_next(st, rowB, st.tap[1]) };
 	f32x2 tp[1][NW + 3];
-	roll_px8<TAPS, P2, 1, NW + 3>(st, pr, pb, nr, nb, tp);
+	roll_px8<TAPS, P2, ODD, 1, NW + 3>(st, pr, pb, nr, nb, tp);
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		f32x2 a = wx[i][0] * tp[0][i];
@@ -443,8 +447,8 @@ __device__ __forceinline__ void roll_wy_rows(cfloat_p roww, int y, f32x2 (&wy)[N
 #endif
 
 /* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
-template <int TAPS, bool P2>
-__device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 (&acc)[4], const u32x4 &idt)
+template <int TAPS, bool P2, bool ODD>
+__device__ __forceinline__ void roll_store(RollState<TAPS, P2, ODD> &st, const f32x2 (&acc)[4], const u32x4 &idt)
 {
 	/* The row offset is added into the vector offset on purpose.  With the row offset in the
 	 * scalar-offset operand hipcc emits no wait state between a 16-byte buffer store and the
@@ -478,7 +482,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 	} else
 #endif
 	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
-	if (__builtin_expect(st.part != 0, 0)) {
+	if (ODD && st.part != 0) {
 		/* the image's last 1-3 columns: one lane, as many dwords (a 16-byte store would run into the next row) */
 		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 		typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
@@ -500,7 +504,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].x, 1, o2);
 	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].y, 3, o2);
 	__builtin_amdgcn_raw_buffer_store_b96(u32x3{ o0, o1, o2 }, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
-	if (__builtin_expect(st.part != 0, 0)) {
+	if (ODD && st.part != 0) {
 		/* the image's last 1-3 columns (a width that is not a multiple of 4): one lane, 3 / 6 / 9 bytes, byte by byte
 		 * (a 12-byte store would run into the next row) */
 		const uint32_t off = st.vo_part + st.so_st;
@@ -517,8 +521,8 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2> &st, const f32x2 
 
 /* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
  * window touches the top or bottom edge: edge rows replicate, fix-ca.c:1218-1256) */
-template <int TAPS, bool P2, int NW>
-__device__ __forceinline__ void roll_row_any(RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
+template <int TAPS, bool P2, bool ODD, int NW>
+__device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                              cfloat_p roww, int y)
 {
 	constexpr int T = TAPS;
@@ -527,7 +531,7 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2> &st, const f32x
 	f32x2 rows[T][4];
 #pragma unroll
 	for (int t = 0; t < T; ++t)
-		roll_hrow<TAPS, P2, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
+		roll_hrow<TAPS, P2, ODD, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
 	f32x2 v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
@@ -548,8 +552,8 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2> &st, const f32x
  * All ring reads of the rows are issued together; the filter arithmetic is written tap-major
  * (for each tap, all rows and outputs) so that consecutive instructions belong to different
  * accumulation chains. */
-template <int TAPS, bool P2, int NW, int NR>
-__device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
+template <int TAPS, bool P2, bool ODD, int NW, int NR>
+__device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                            const RollBlock &bn, cfloat_p roww, int y)
 {
 	constexpr int T = TAPS;
@@ -592,7 +596,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
-	roll_px8<TAPS, P2, NR, NP>(st, pr, pb, nr, nb, tp);
+	roll_px8<TAPS, P2, ODD, NR, NP>(st, pr, pb, nr, nb, tp);
 #pragma unroll
 	for (int t = 0; t < NW; ++t)
 #pragma unroll
@@ -632,8 +636,13 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2> &st, const f32x2 
 	STAMP(4);                                       /* conversions + stores */
 }
 
-/* one tile: output rows [Y0, Y0 + nrows) of strip `strip` of image `img` */
-template <int TAPS, bool P2>
+/* one tile: output rows [Y0, Y0 + nrows) of strip `strip` of image `img`.
+ * ODD: the tile may end in a lane of 1-3 pixels, or read its own pixels from a ring offset that is not lane-aligned: the
+ * last strips of an image whose width is not a multiple of 4.  Such images run their own instantiation of the kernel
+ * (wave-uniform branches per row in every strip); for all others the code is compiled out: as scalar branches in the one
+ * kernel it cost the single-image launch 1.2 points (RGB8: 2.1), as a second variant inside the one kernel 0.7 (1.9:
+ * scalar registers spilled). */
+template <int TAPS, bool P2, bool ODD>
 __device__ __forceinline__ void
 roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPlan &pl, const RollTables &tb,
           int img, int strip, int Y0, int nrows, int edge_wb)
@@ -645,7 +654,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	const int W = g.W, H = g.H, oc = pl.oc;
 	const int X0 = strip * oc;                      /* the last strip may be narrower: its extra lanes store nothing */
 
-	RollState<TAPS, P2> st;
+	RollState<TAPS, P2, ODD> st;
 	st.lane = threadIdx.x;
 	ROLL_EXP_BEGIN(st);
 	st.KM = pl.ring - 1;
@@ -736,9 +745,9 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 			 * whole block to come back */
 			RollBlock bn = b;
 			if (r + step < nrows) bn = load_block(blocks, y + step);
-			if (four)     roll_block<TAPS, P2, NW, NRB>(st, wx, b, bn, roww, y);
-			else if (one) roll_block<TAPS, P2, NW, 1>(st, wx, b, bn, roww, y);
-			else          roll_row_any<TAPS, P2, NW>(st, wx, b, roww, y);
+			if (four)     roll_block<TAPS, P2, ODD, NW, NRB>(st, wx, b, bn, roww, y);
+			else if (one) roll_block<TAPS, P2, ODD, NW, 1>(st, wx, b, bn, roww, y);
+			else          roll_row_any<TAPS, P2, ODD, NW>(st, wx, b, roww, y);
 			r += step;
 			b = bn;
 		}
@@ -755,7 +764,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 #else
 #define ROLL_OCC
 #endif
-template <int TAPS, bool P2>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC */
+template <int TAPS, bool P2, bool ODD>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC; ODD: the image's width is not a multiple of 4 */
 __global__ __launch_bounds__(64) ROLL_OCC void
 k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 {
@@ -770,7 +779,7 @@ k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 	if (tile >= sc.pool_waves) return;
 	const int strip = tile % pl.nstrips, chunk = tile / pl.nstrips;
 	const int Y0 = g.y1 + chunk * sc.th;
-	roll_tile<TAPS, P2>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0), sc.edge_wb);
+	roll_tile<TAPS, P2, ODD>(lds, imgs, g, pl, tb, img, strip, Y0, min(sc.th, g.y2 - Y0), sc.edge_wb);
 }
 
 /* ======================================================================================
@@ -1169,26 +1178,27 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 	if (e != hipSuccess) return e;
 	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	lds += (size_t)fixca_debug_env("FIXCA_EXP_LDS_PAD", 0, 0, 128 * 1024);      /* timing experiment: fewer waves per CU */
-	const bool p2 = (pl->ring & (pl->ring - 1)) == 0;
-	{
-		const void *fn = p2 ? (g->interp == 0 ? (const void *)k_roll<1, true> : g->interp == 1 ? (const void *)k_roll<2, true> : (const void *)k_roll<4, true>)
-		                    : (g->interp == 0 ? (const void *)k_roll<1, false> : g->interp == 1 ? (const void *)k_roll<2, false> : (const void *)k_roll<4, false>);
-		e = (hipError_t)fixca_dyn_lds(fn, 96 * 1024);
-		if (e != hipSuccess) return e;
-	}
+	const bool p2 = (pl->ring & (pl->ring - 1)) == 0, odd = (g->W & 3) != 0;
 	RollSched sc;
 	roll_make_sched(g, pl, n_images, &sc);
 	const dim3 grid((unsigned)sc.pool_blocks * (unsigned)n_images);
-	if (p2) {
-		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-		else                     hipLaunchKernelGGL((k_roll<4, true>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-	} else {
-		if (g->interp == 0)      hipLaunchKernelGGL((k_roll<1, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-		else if (g->interp == 1) hipLaunchKernelGGL((k_roll<2, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-		else                     hipLaunchKernelGGL((k_roll<4, false>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
-	}
-	e = hipGetLastError();
+	auto launch = [&](auto taps_tag, auto p2_tag, auto odd_tag) -> hipError_t {
+		constexpr int TP = decltype(taps_tag)::value;
+		constexpr bool P2 = decltype(p2_tag)::value, OD = decltype(odd_tag)::value;
+		hipError_t ea = (hipError_t)fixca_dyn_lds((const void *)k_roll<TP, P2, OD>, 96 * 1024);
+		if (ea != hipSuccess) return ea;
+		hipLaunchKernelGGL((k_roll<TP, P2, OD>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
+		return hipGetLastError();
+	};
+	auto by_odd = [&](auto taps_tag, auto p2_tag) -> hipError_t {
+		return odd ? launch(taps_tag, p2_tag, std::true_type{}) : launch(taps_tag, p2_tag, std::false_type{});
+	};
+	auto by_p2 = [&](auto taps_tag) -> hipError_t {
+		return p2 ? by_odd(taps_tag, std::true_type{}) : by_odd(taps_tag, std::false_type{});
+	};
+	if (g->interp == 0)      e = by_p2(std::integral_constant<int, 1>{});
+	else if (g->interp == 1) e = by_p2(std::integral_constant<int, 2>{});
+	else                     e = by_p2(std::integral_constant<int, 4>{});
 	if (e != hipSuccess) return e;
 	return tables_mark_used(entry, stream);
 }
