@@ -19,25 +19,38 @@ CSRC = os.path.join(ROOT, "gimp-fix-ca_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def _asm(tmp_path_factory, source):
+def _asm(tmp_path_factory, source, skip_kernels=None, only_kernels=None):
+    """instruction lines of the translation unit; skip_kernels / only_kernels: a regex on the mangled names of kernels to
+    leave out / to keep"""
     if not os.path.exists(HIPCC) and not shutil.which("hipcc"):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("isa") / (source + ".s")
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
                            "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
-    return [l for l in out.read_text().split("\n")
-            if l.startswith("\t") and not l.strip().startswith((";", "."))]
+    lines, skipping = [], False
+    for l in out.read_text().split("\n"):
+        m = re.match(r"(_Z\w+):", l)
+        if m:
+            skipping = bool(skip_kernels and re.search(skip_kernels, m.group(1))) or bool(only_kernels and not re.search(only_kernels, m.group(1)))
+        if not skipping and l.startswith("\t") and not l.strip().startswith((";", ".")):
+            lines.append(l)
+    return lines
+
+
+# k_roll<TAPS, P2, true> is the instantiation for widths that are not multiples of 4 (a lane of 1-3 pixels, the lane's own
+# pixels read through a byte shift): the properties below are those of the common kernel, k_roll<TAPS, P2, false>
+ODD_WIDTH_KERNELS = r"k_roll(_rgb)?ILi\dELb[01]ELb1EEE"
 
 
 @pytest.fixture(scope="module")
 def roll_asm(tmp_path_factory):
-    return _asm(tmp_path_factory, "fixca_roll.hip")
+    return _asm(tmp_path_factory, "fixca_roll.hip", ODD_WIDTH_KERNELS)
 
 
 @pytest.fixture(scope="module")
 def roll_rgb_asm(tmp_path_factory):
-    return _asm(tmp_path_factory, "fixca_roll_rgb.hip")
+    return _asm(tmp_path_factory, "fixca_roll_rgb.hip", ODD_WIDTH_KERNELS)
 
 
 def _dst_regs(line):
@@ -81,6 +94,19 @@ def test_rgb8_tap_windows_are_picked_by_conversion_not_by_shifts(roll_rgb_asm):
     stores = [l.strip() for l in roll_rgb_asm if l.strip().startswith("buffer_store_dwordx3")]
     assert stores
     for st in stores:                                   # same store rule as RGBA: the scalar offset is the literal 0
+        ops = [o.strip() for o in st.split(None, 1)[1].split(",")]
+        assert ops[3].split()[0] == "0", st
+
+
+@pytest.mark.parametrize("source", ["fixca_roll.hip", "fixca_roll_rgb.hip"])
+def test_odd_width_instantiations_keep_the_hazard_rules(tmp_path_factory, source):
+    """k_roll<TAPS, P2, true> (widths that are not multiples of 4): the hand-written DPP conversions still read LDS-load
+    results only, and every 12 / 16-byte row store still has the literal 0 as its scalar offset"""
+    asm = _asm(tmp_path_factory, source, only_kernels=ODD_WIDTH_KERNELS)
+    _check_dpp(asm, 16)
+    stores = [l.strip() for l in asm if l.strip().startswith(("buffer_store_dwordx3", "buffer_store_dwordx4"))]
+    assert stores
+    for st in stores:
         ops = [o.strip() for o in st.split(None, 1)[1].split(",")]
         assert ops[3].split()[0] == "0", st
 
