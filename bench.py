@@ -71,6 +71,11 @@ CONFIGS = [
     dict(name="RGB u32 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=4, params=dict(PARAMS, interpolation=1), images=32),
     dict(name="RGBA u32 cubic, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=PARAMS, images=32),
     dict(name="RGBA u32 linear, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=4, params=dict(PARAMS, interpolation=1), images=32),
+    # widths that are not multiples of 4 (three of four arbitrary crops): the main kernel since round 4, before that the
+    # register-window kernels at 19-25 %
+    dict(name="RGBA8 cubic, 5999 wide, lens (658,1280), 5999x4000", w=5999, h=4000, c=4, bpc=1, params=PARAMS),
+    dict(name="RGB8 cubic, 5999 wide, lens (658,1280), 5999x4000", w=5999, h=4000, c=3, bpc=1, params=PARAMS),
+    dict(name="RGB u16 cubic, 5999 wide, lens (658,1280), 5999x4000", w=5999, h=4000, c=3, bpc=2, params=PARAMS, images=64),
 ]
 
 
@@ -179,15 +184,15 @@ KID_LIN = 9                      # ... of the LDS-ring LINEAR kernel of the wide
 KID_CUB = 10                     # ... of the LDS-ring CUBIC kernel of the wide RGBA formats: likewise
 
 
-def kernel_name(kid, plan_text):
-    """the device function a plan runs, from the planner's own description"""
+def kernel_name(kid, plan_text, width=0):
+    """the device function a plan runs, from the planner's own description (width: the image's, for the row-rolling
+    kernel's third template argument: its instantiation for widths that are not multiples of 4)"""
     words = plan_text.split()
     if kid == KID_ROLL:
         taps = {"none": 1, "linear": 2, "cubic": 4}[words[1]]
         ring = int([w for w in words if w.startswith("ring=")][0][5:])
         rgb = "bpp=3" in words
-        # the third template argument: the instantiation for widths that are not multiples of 4 (never the bench's images)
-        return "k_roll%s<%d,%s,false>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false")
+        return "k_roll%s<%d,%s,%s>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false", "true" if width % 4 else "false")
     return {"exact-fp64": "k_exact/k_wide", "fast-none": "k_none", "fast-interp": "k_interp", "scan": "k_scan", "scanw": "k_scanw",
             "wide-roll-fp64": "k_wcol", "move-none": "k_move", "ring-linear-fp64": "k_lin", "ring-cubic-fp64": "k_cub"}.get(words[0], words[0])
 
@@ -260,7 +265,7 @@ def run_configs(torch, fixca, dev, per_launch):
                 md = float((dsts[0].view(dt).to(torch.float64) - exact.view(dt).to(torch.float64)).abs().max())
             # the row-rolling kernel (plan id 6) takes up to per_launch images in one launch, the kernels of the wide sample types (7 - 10) up to 128; every other kernel is one launch per image
             ipl = min(n, per_launch, 128) if kid in (KID_ROLL, KID_WCOL, KID_MOVE, KID_LIN, KID_CUB) else 1
-            entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc), "images_per_launch": ipl, "launches_timed": reps * ((n + per_launch - 1) // per_launch if ipl > 1 else n),
+            entry.update({"kernel_plan": desc, "kernel": kernel_name(kid, desc, w), "images_per_launch": ipl, "launches_timed": reps * ((n + per_launch - 1) // per_launch if ipl > 1 else n),
                           "us_per_image": round(us, 2), "GBs": round(algo / us / 1e3, 1),
                           "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4), "mpix_s": round(w * h / us, 1),
                           "max_abs_diff_vs_fp64_kernel": md})
@@ -367,7 +372,7 @@ def compact_line(full):
         roof["min_config_frac"] = worst["frac"]
         roof["min_config"] = worst["name"].split(",")[0]
         line["configs_columns"] = ["name", "us_per_image", "frac_of_8TBs", "kernel", "images_per_launch", "max_abs_diff_vs_fp64_kernel"]
-        line["configs"] = [[c["name"].replace(", lens (658,1280), 6000x4000", "").replace(", 6000x4000", ""), c["us_per_image"], c["frac"],
+        line["configs"] = [[c["name"].replace(", lens (658,1280), 6000x4000", "").replace(", lens (658,1280), 5999x4000", "").replace(", 6000x4000", ""), c["us_per_image"], c["frac"],
                             c["kernel"], c["images_per_launch"], c["max_abs_diff_vs_fp64_kernel"]] for c in cfgs]
         line["configs"] += [[c["name"], "error: " + c["error"][:80]] for c in full["configs"] if "error" in c]
     line["roofline"] = roof
@@ -702,7 +707,7 @@ def main():
                        "kernel_plan": plan_text},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kernel_name(kid, plan_text), "kernel_us": round(kernel_ms * 1e3, 2),
+                         "kernel": kernel_name(kid, plan_text, W), "kernel_us": round(kernel_ms * 1e3, 2),
                          "launches_timed": args.steps * launches_per_step,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "images_per_launch": imgs_per_launch, "us_per_image": round(kernel_ms * 1e3 / imgs_per_launch, 2)},
