@@ -98,10 +98,10 @@ FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, i
  * kernel id, or a negative FIXCA_E_* if the call itself would be refused:
  *   1 exact-fp64      one thread per pixel, the reference's arithmetic operation for operation
  *                     (every sample type; FIXCA_KERNEL_EXACT, and the fallback of the wide types)
- *   2 fast-none       8-bit register-window gather (widths the ring kernels refuse)
+ *   2 fast-none       8-bit register-window gather (images narrower than 256 pixels, shifts the ring kernels refuse)
  *   3 fast-interp     8-bit register-window LINEAR / CUBIC (likewise)
  *   4 scan            8-bit LDS-ring row scan (scales far from 1)
- *   6 roll            8-bit LDS-ring row-rolling kernel, RGBA8 and RGB8: the main kernel
+ *   6 roll            8-bit LDS-ring row-rolling kernel, RGBA8 and RGB8 of any width from 256 pixels: the main kernel
  *   7 wide-roll-fp64  u16 / u32 / float / double, LINEAR and CUBIC, fp64 rolling window
  *   8 move-none       u16 / u32 / float / double, NONE: LDS-ring byte mover
  *   9 ring-linear-fp64 u32 / float / double, RGBA and RGB, LINEAR: LDS ring + fp64 bilinear
