@@ -155,6 +155,8 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 		stoff[i] = (U < nunits - (tail_dw ? 1 : 0)) ? (uint32_t)(X0 * PB + 16 * U) : dst_bytes;
 	}
 	const int tail_u = (nunits - 1) >> 6, tail_lane = (nunits - 1) & 63;
+	const int nbytes_row = (xe - X0) * PB;             /* bytes of the strip's output row */
+	uint32_t row_phase = (uint32_t)(uintptr_t)dst + (uint32_t)Y0 * pitch + (uint32_t)X0 * PB;      /* mod 2^32: only the low 6 bits are used */
 
 	/* ---- the ring (as in k_move) ---------------------------------------------------------------------------------------- */
 	const uint32_t vo_ld = (uint32_t)U0 * PB + 16u * (uint32_t)lane;
@@ -280,10 +282,32 @@ k_lin(MoveBatch imgs, FixcaGeom g, MovePlan mp)
 			}
 			out[i] = v;
 		}
-		/* scalar offset the constant 0: the store-data hazard of profiles/NOTES.md (tests/test_host_logic.py scans for it) */
+		/* scalar offset the constant 0: the store-data hazard of profiles/NOTES.md (tests/test_host_logic.py scans for it).
+		 * A row whose strip does not start and end on 64-byte boundaries (a pitch that is not a multiple of 64: RGBA float of
+		 * a width that is not a multiple of 4; 6002 wide 68.0 against 72.4 % at 6000) shares its end sectors with the
+		 * neighbour strip's wave: in launches of several images the lanes there store write-back, as in k_roll. */
+		bool split = false;
+		uint32_t a0 = 0, endb = 0;
+		if (__builtin_expect(mp.edge_wb != 0, 0)) {
+			a0 = row_phase & 63u;
+			endb = a0 + (uint32_t)nbytes_row;
+			row_phase += pitch;
+			split = (a0 | (endb & 63u)) != 0;
+		}
+		if (__builtin_expect(split, 0)) {
 #pragma unroll
-		for (int i = 0; i < NU; ++i)
-			__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);
+			for (int i = 0; i < NU; ++i) {
+				const uint32_t first = 16u * (uint32_t)(lane + 64 * i) + a0;
+				const bool edge = (a0 != 0 && first < 64u) || ((endb & 63u) != 0 && ((first + 15u) >> 6) >= ((endb - 1) >> 6));
+				const uint32_t off = stoff[i] == dst_bytes ? dst_bytes : stoff[i] + so_st;
+				__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, edge ? dst_bytes : off, 0, 2);
+				__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, edge ? off : dst_bytes, 0, 0);
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < NU; ++i)
+				__builtin_amdgcn_raw_buffer_store_b128(out[i], rs_dst, stoff[i] + so_st, 0, 2);
+		}
 		if (tail_dw) {                                  /* u16 images of odd width: the row's last unit is half a unit */
 #pragma unroll
 			for (int i = 0; i < NU; ++i)
@@ -556,6 +580,7 @@ fixca_launch_lin_batch(const void *const *d_src, void *const *d_dst, int n_image
 	if (ea != hipSuccess) return ea;
 	MovePlan mp;
 	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.depth = pl->depth; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
+	mp.edge_wb = fixca_debug_env("FIXCA_EDGE_WB", n_images > 1 ? 1 : 0, 0, 1);
 	MoveBatch imgs;
 	for (int i = 0; i < MOVE_BATCH_MAX; ++i) {
 		imgs.src[i] = static_cast<const unsigned char *>(d_src[i < n_images ? i : 0]);

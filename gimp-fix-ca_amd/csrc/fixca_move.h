@@ -36,6 +36,8 @@ struct MovePlan {
 	int ring;           /* source rows in the LDS ring                                                     */
 	int depth;          /* source rows kept in flight beyond the newest row in use                         */
 	int nstrips, nwaves, nblocks;
+	int edge_wb;        /* k_lin, RGBA: in launches of several images the lanes on a strip's partial end sectors store write-back
+	                       (as k_roll: fixca_roll.hip, roll_store); 0 in a launch of one image and in the other kernels */
 };
 
 #endif

@@ -363,6 +363,7 @@ fixca_launch_move_batch(const void *const *d_src, void *const *d_dst, int n_imag
 	if (ea != hipSuccess) return ea;
 	MovePlan mp;
 	mp.ocpx = pl->oc; mp.th = pl->th; mp.ring = pl->ring; mp.depth = pl->depth; mp.nstrips = pl->nstrips; mp.nwaves = pl->nwaves; mp.nblocks = pl->nblocks;
+	mp.edge_wb = 0;
 	MoveBatch imgs;
 	for (int i = 0; i < MOVE_BATCH_MAX; ++i) {
 		imgs.src[i] = static_cast<const unsigned char *>(d_src[i < n_images ? i : 0]);

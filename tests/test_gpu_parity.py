@@ -513,6 +513,40 @@ def test_wide_rolling_kernel_bit_exact(torch_cuda, bpc, dtype, shape):
         assert np.all(got[:7] == 0x5A) and np.all(got[h - 3:] == 0x5A)
 
 
+@pytest.mark.parametrize("bpc,dtype", [(4, np.uint32), (-4, np.float32), (-8, np.float64)], ids=lambda v: str(v))
+@pytest.mark.parametrize("w", [362, 363, 1201])
+def test_ring_linear_kernel_batch_unaligned_pitch(torch_cuda, bpc, dtype, w):
+    """k_lin in a launch of several RGBA images whose pitch is not a multiple of 64 bytes (float / u32: a width that is not
+    a multiple of 4; double: an odd width): the lanes on a strip's partial end sectors store write-back, the others nt, in
+    two instructions.  Every byte written exactly once: the oracle's bytes, the guard bytes between the images intact."""
+    torch = torch_cuda
+    h, sb = 70, abs(bpc)
+    p = fixca.make_params(blue=1.25, red=-0.75, lens_x=w // 3, lens_y=30, interpolation=1, x_blue=0.5, y_red=-1.5)
+    kid, desc = fixca.plan(w, h, 4 * sb, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
+    assert kid == 9, desc
+    imgs = [_wide_image(dtype, w, h, 4, 0x11AE + w + i) for i in range(3)]
+    refs = [pyoracle.region(a, pyoracle.make_params(**p.as_dict()), bpc=bpc).view(np.uint8).reshape(h, w, 4 * sb) for a in imgs]
+    n = w * h * 4 * sb
+    gap = [48, 16, 32]
+    buf = torch.full((3 * (n + 64) + 256,), 0x3C, dtype=torch.uint8, device="cuda")
+    srcs = [torch.from_numpy(a.view(np.uint8).reshape(h, w, 4 * sb)).cuda() for a in imgs]
+    dsts, at = [], 0
+    for i in range(3):
+        at += gap[i]
+        dsts.append(buf[at:at + n].view(h, w, 4 * sb))
+        at += n
+    fixca.fix_ca_batch(srcs, dsts, w, h, 4 * sb, bpc, p)
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    at = 0
+    for i in range(3):
+        assert (host[at:at + gap[i]] == 0x3C).all()
+        at += gap[i]
+        assert host[at:at + n].tobytes() == refs[i].tobytes(), (desc, i)
+        at += n
+    assert (host[at:] == 0x3C).all()
+
+
 MOVE_PARAMS = [
     dict(blue=2.0, red=-2.0, lens_x=0.3, lens_y=0.4),                                         # the configs' lateral CA
     dict(blue=-7.5, red=9.0, lens_x=-1, lens_y=-1, y_blue=11.0, x_red=-13.5),                  # steps inside strips and tiles, large shifts
