@@ -593,6 +593,27 @@ static bool move_cols_fit(const FixcaGeom *g, int ocpx, int winb)
 	return true;
 }
 
+/* Strip widths of the ring kernels of the wide sample types (k_move, k_lin, k_cub).  `widest` is the widest strip whose
+ * windows fit a ring row.  A strip whose byte width is a multiple of 64 starts and ends every row store on a sector
+ * boundary when the pitch does too, and no sector is shared with the neighbour strip's wave (round 4,
+ * profiles/r04_wide_strip_widths.txt: RGBA u16 NONE 252 / 248 / 240 columns 71.8 / 74.3 / 74.8 %, u16 LINEAR 63.9 / 65.7 /
+ * 66.2 %, RGBA float CUBIC 58 / 56 columns 59.5 / 61.0 %, RGB u16 NONE 328 / 320: 71.0 / 71.7 %; 15 % narrower loses again:
+ * float CUBIC 52 / 48 columns 57.5 / 54.3 %).  Among such widths within 10 % of the widest: the fewest strips, then the
+ * fewest idle lanes in the image's last strip (6000 wide: 248 and 240 columns both make 25 strips, 240 makes them full). */
+template <typename Fits>
+static int sector_aligned_strip(int W, int pb, int step, int widest, bool forced, Fits fits)
+{
+	if (forced || widest <= 0) return widest;
+	int best = 0;
+	long best_n = 0, best_pad = 0;
+	for (int oc = widest; oc >= step && 10 * oc >= 9 * widest; oc -= step) {
+		if (((long long)oc * pb) % 64 != 0 || !fits(oc)) continue;
+		const long n = (W + oc - 1) / oc, pad = n * oc;
+		if (!best || n < best_n || (n == best_n && pad < best_pad)) { best = oc; best_n = n; best_pad = pad; }
+	}
+	return best ? best : widest;
+}
+
 static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 {
 	if (g->interp != 0 || g->bpc == 1) return false;
@@ -639,6 +660,7 @@ static bool plan_move(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		for (int oc = oc_top; oc >= step && oc * pb >= winb / 2 && !oc_pick; oc -= step)
 			if (move_cols_fit(g, oc, winb)) oc_pick = oc;
 		if (!oc_pick) continue;
+		oc_pick = sector_aligned_strip(W, pb, step, oc_pick, oc_env != 0, [&](int oc) { return move_cols_fit(g, oc, winb); });
 		pl->kernel = FIXCA_K_MOVE;
 		pl->nu = nu;
 		pl->depth = depth;
@@ -753,6 +775,7 @@ static bool plan_lin(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		for (int oc = oc_top; oc >= step && oc * pb >= winb / 2 && !oc_pick; oc -= step)
 			if (lin_cols_fit(g, oc, winb)) oc_pick = oc;
 		if (!oc_pick) continue;
+		oc_pick = sector_aligned_strip(W, pb, step, oc_pick, oc_env != 0, [&](int oc) { return lin_cols_fit(g, oc, winb); });
 		pl->kernel = FIXCA_K_LIN;
 		pl->wide_fast = fast ? 1 : 0;
 		pl->nu = nu;
@@ -857,6 +880,7 @@ static bool plan_cub(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 		for (int oc = oc_top; oc >= step && oc * pb >= winb / 2 && !oc_pick; oc -= step)
 			if (cub_cols_fit(g, oc, winb)) oc_pick = oc;
 		if (!oc_pick) continue;
+		oc_pick = sector_aligned_strip(W, pb, step, oc_pick, oc_env != 0, [&](int oc) { return cub_cols_fit(g, oc, winb); });
 		pl->kernel = FIXCA_K_CUB;
 		pl->nu = nu;
 		pl->depth = depth;
