@@ -19,17 +19,22 @@ CSRC = os.path.join(ROOT, "gimp-fix-ca_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+_ASM_CACHE = {}
+
+
 def _asm(tmp_path_factory, source, skip_kernels=None, only_kernels=None):
-    """instruction lines of the translation unit; skip_kernels / only_kernels: a regex on the mangled names of kernels to
-    leave out / to keep"""
+    """instruction lines of the translation unit (compiled once per source and test session); skip_kernels / only_kernels:
+    a regex on the mangled names of kernels to leave out / to keep"""
     if not os.path.exists(HIPCC) and not shutil.which("hipcc"):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / (source + ".s")
-    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                           "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
+    if source not in _ASM_CACHE:
+        out = tmp_path_factory.mktemp("isa") / (source + ".s")
+        subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                               "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out),
+                               os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
+        _ASM_CACHE[source] = out.read_text().split("\n")
     lines, skipping = [], False
-    for l in out.read_text().split("\n"):
+    for l in _ASM_CACHE[source]:
         m = re.match(r"(_Z\w+):", l)
         if m:
             skipping = bool(skip_kernels and re.search(skip_kernels, m.group(1))) or bool(only_kernels and not re.search(only_kernels, m.group(1)))
