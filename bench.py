@@ -220,7 +220,11 @@ def time_batch(torch, fixca, srcs, dsts, w, h, bytes_pp, bpc, params, per_launch
     def one_pass():
         for s, d in groups:
             fixca.fix_ca_batch(s, d, w, h, bytes_pp, bpc, params)
-    one_pass()
+    # untimed passes first: the configuration's images were just allocated and filled (short kernels, pauses), and the
+    # clocks take a few milliseconds of this kernel's load to settle: one pass read config 3 three points under the
+    # headline of the same run (68.8-69.8 against 71.8-72.8 %, same kernel, same parameters)
+    for _ in range(max(2, 512 // n)):
+        one_pass()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
