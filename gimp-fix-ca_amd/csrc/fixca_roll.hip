@@ -202,7 +202,7 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2, ODD> &st)
 {
 	++st.ld;
 	[[maybe_unused]] const int slot = roll_slot(st, st.ld);
-#if defined(__HIP_DEVICE_COMPILE__)       /* the host pass of hipcc does not know this builtin */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ROLL_ABL_NOLOAD)       /* the host pass of hipcc does not know this builtin; ROLL_ABL_NOLOAD: timing experiment, no ring fill */
 #if ROLL_BPP == 4
 	__attribute__((address_space(3))) uint8_t *row = (__attribute__((address_space(3))) uint8_t *)(st.ring + slot * RING_ROW);
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(st.rs_src, (__attribute__((address_space(3))) void *)row, 16, st.vo_ld, st.so_ld, 0, ROLL_LD_AUX);
@@ -723,6 +723,9 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	/* a lane without output stores at the buffer's size: past the end whether or not the range
 	 * check adds the row offset (the size is below 2 GB, so the sum cannot wrap) */
 	st.vo_st = (lane < nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
+#ifdef ROLL_ABL_NOSTORE            /* timing experiment (never the shipped library): every store out of range */
+	st.vo_st = dst_bytes;
+#endif
 	st.so_st = 0;
 	st.part = wcols & 3;
 	st.vo_part = (st.part && lane == nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
