@@ -106,9 +106,14 @@ FIXCA_API int fixca_batch_device(const void *const *d_src, void *const *d_dst, i
  *   8 move-none       u16 / u32 / float / double, NONE: LDS-ring byte mover
  *   9 ring-linear-fp64 u32 / float / double, RGBA and RGB, LINEAR: LDS ring + fp64 bilinear
  *  10 ring-cubic-fp64  RGBA double (and float in batches), CUBIC: LDS ring + a rolling window per lane
- * (5 is retired.)  Usable with no GPU: nothing is launched.  For LINEAR / CUBIC on the wide
- * sample types the planner asks the HIP runtime for the current device's occupancy (this
- * may initialise the runtime); without a device it plans for a 256-CU part.
+ * (5 is retired.)  Usable with no GPU: no pixel kernel is launched.  Two questions go to the
+ * device when there is one: for LINEAR / CUBIC on the wide sample types the current device's
+ * occupancy (this may initialise the runtime; without a device the planner assumes a 256-CU
+ * part), and, the first time a geometry's rows are not whole dwords (RGB8 of a width that is
+ * not a multiple of 4, RGB u16 of odd width), whether the device moves dwords at byte
+ * addresses faithfully: a one-wave probe on a 4-KiB scratch, once per device and process
+ * (without a device: assumed).  Like the first call of a geometry, such a first call must
+ * not happen inside a stream capture.
  */
 FIXCA_API int fixca_plan_describe(int orig_width, int orig_height, int bytes, int bpc,
                                   const FIXCA_PARAMS_T *params, int x1, int x2, int y1, int y2,
