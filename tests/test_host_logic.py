@@ -244,3 +244,25 @@ def test_ring_kernel_plans_fall_back():
         assert fixca.plan(6000, 4000, 16, -4, fixca.make_params(blue=2.0, red=-2.0, lens_x=100, lens_y=50, interpolation=1))[0] == 7
     finally:
         del os.environ["FIXCA_NO_LIN"]
+
+
+def test_bench_line_stays_small_and_carries_the_evidence():
+    """the driver's record keeps the fixed keys (roofline whole, scalars only) and about 8 KB of output: the line bench.py
+    prints must stay under 6 KB and hold, inside `roofline`, the figures a reader needs first (a full record of a real run,
+    profiles/r04t_bench_full.json, through bench.compact_line)"""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r04t_bench_full.json")))
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < 6144
+    roof = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "single_image_us", "single_image_frac", "copy_frac",
+              "oracle_max_abs_diff", "oracle_differing", "rgb8_frac", "min_config_frac", "min_config"):
+        assert k in roof, k
+    assert all(not isinstance(v, (dict, list)) for v in roof.values())      # scalars only: nested values are dropped from the record
+    assert line["metric"] == full["metric"] and line["cpu_baseline"]["kind"] == "port"
+    assert len(line["configs"]) == len(bench.CONFIGS) and len(line["configs_columns"]) == len(line["configs"][0])
