@@ -153,6 +153,9 @@ bool fixca_debug_flag(const char *name)
 
 static int env_int(const char *name, int dflt, int lo, int hi) { return fixca_debug_env(name, dflt, lo, hi); }
 
+/* FIXCA_DEBUG=1 FIXCA_PLAN_TRACE=1: why a planner refused a geometry, on stderr */
+#define PLAN_REFUSE(...) do { if (fixca_debug_flag("FIXCA_PLAN_TRACE")) { fprintf(stderr, "fixca-plan: " __VA_ARGS__); fputc('\n', stderr); } return false; } while (0)
+
 /* does every strip's source window fit the 256 columns a wave filters? */
 static bool interp_fits(const FixcaGeom *g, int oc, int taps)
 {
@@ -283,44 +286,61 @@ static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int
 
 /* Every strip must satisfy what k_roll assumes: with m = min over the strip of (tap column - x),
  * every tap with weight lands on pixel i + j of the lane's 8, 0 <= j <= 4; the lane windows
- * start at most 4 px before and end at most 16 px past the 256-column ring row (the pads);
- * every column that carries weight is inside the ring row. */
+ * start at most 16 px before and end at most 16 px past the 256-column ring row (the pads);
+ * every column that carries weight is inside the ring row.
+ * Outputs that ARE the row's first or last pixel (a coordinate clamped to the image: all the weight on column 0 or
+ * W - 1) do not count towards m and the 5-pixel reach: the ones the 5 pixels do not reach are overwritten by the
+ * kernel (fixca_roll.hip, roll_edge_px; k_roll_tables takes the same decisions on the same fp64 values) and make the
+ * plan one for the instantiation that does so (*edge). */
 static int roll_win(const FixcaGeom *g) { return g->bpp == 3 ? ROLL_WIN_RGB : ROLL_WIN; }
 
-static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps)
+static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps, int *edge)
 {
+	*edge = 0;
 	const int WIN = roll_win(g);
 	const int back = (taps == 4) ? 1 : 0, W = g->W;
 	const int nstrips = (W + oc - 1) / oc;
 	for (int st = 0; st < nstrips; ++st) {
 		const int X0 = st * oc;                         /* k_roll's last strip may be narrower */
 		const int xe = X0 + oc < W ? X0 + oc : W;
-		int lo = X0, hi = xe - 1, m[2];
+		int lo = X0, hi = xe - 1, m[2], sides = 0;      /* sides: 1 flagged first-pixel outputs, 2 last-pixel */
 		for (int c = 0; c < 2; ++c) {
 			int a = taps == 1 ? h_map_int(X0, g->xc, W, g->s[c], g->xs[c])
 			                  : clampi((int)floor(h_map_dbl(X0, g->xc, W, g->s[c], g->xs[c])) - back, 0, W - 1);
 			if (a < lo) lo = a;
 		}
 		for (int c = 0; c < 2; ++c) {
-			int mn = INT_MAX, mx = INT_MIN;
+			int mn = INT_MAX, mx = INT_MIN, mn_all = INT_MAX, mx_all = INT_MIN;
 			for (int x = X0; x < xe; ++x) {
 				int f, l;
 				tap_span(g, c, x, taps, &f, &l);
+				if (l > hi) hi = l;
+				if (f - x < mn_all) mn_all = f - x;
+				if (l - x > mx_all) mx_all = l - x;
+				if (f < lo) PLAN_REFUSE("roll oc=%d strip %d channel %d: column %d taps %d, below the window start %d", oc, st, c, x, f, lo);               /* the window start assumes the first column needs the lowest tap */
+				if (f == l && (f == 0 || f == W - 1)) continue;          /* an edge pixel */
 				if (f - x < mn) mn = f - x;
 				if (l - x > mx) mx = l - x;
-				if (l > hi) hi = l;
-				if (f < lo) return false;               /* the window start assumes the first column needs the lowest tap */
 			}
-			if (mx - mn > 4) return false;
+			if (mx_all - mn_all <= 4) { m[c] = mn_all; continue; }      /* the 5 pixels reach everything: edge pixels are outputs like any others */
+			if (mn == INT_MAX) mn = mx = 0;                              /* a strip of edge pixels only */
+			if (mx - mn > 4) PLAN_REFUSE("roll oc=%d strip %d channel %d: tap offsets span %d..%d (more than 5 lane pixels)", oc, st, c, mn, mx);
+			for (int x = X0; x < xe; ++x) {
+				int f, l;
+				tap_span(g, c, x, taps, &f, &l);
+				if (!(f == l && (f == 0 || f == W - 1))) continue;
+				if (f - x - mn < 0 || f - x - mn > 4) { *edge = 1; sides |= (f == 0) ? 1 : 2; }
+			}
+			if (sides == 3) PLAN_REFUSE("roll oc=%d strip %d: edge pixels of both sides", oc, st);    /* the kernel reads one edge pixel per row and strip */
 			m[c] = mn;
 		}
 		int U0 = lo & ~ROLL_U0_MASK;
 		if (U0 > W - WIN) U0 = W - WIN;
-		if (hi > U0 + WIN - 1) return false;
+		if (hi > U0 + WIN - 1) PLAN_REFUSE("roll oc=%d strip %d: columns %d..%d do not fit the %d-column window at %d", oc, st, lo, hi, WIN, U0);
 		const int nact = (xe - X0 + 3) >> 2;            /* producing lanes (the last may be partial); lane `nact` is read as a neighbour */
 		for (int c = 0; c < 2; ++c) {
 			const int P = X0 + m[c] - U0;
-			if (P < -4 || P + 4 * nact + 4 > WIN + 16) return false;
+			if (P < -16 || P + 4 * nact + 4 > WIN + 16) PLAN_REFUSE("roll oc=%d strip %d channel %d: lane windows start at %d (pads allow -16 .. %d)", oc, st, c, P, WIN + 16 - 4 * nact - 4);
 		}
 	}
 	return true;
@@ -340,7 +360,7 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	 * every KB of ring is a wave less per CU (160 KB of LDS) */
 	int ring = env_int("FIXCA_RING", 0, 0, 64);
 	if (ring == 0) ring = (span + 7 <= 8) ? 8 : (span + 7 <= 16) ? 16 : span + 9;
-	if (ring > 64 || span + 5 > ring) return false;
+	if (ring > 64 || span + 5 > ring) PLAN_REFUSE("roll: span %d needs a ring of %d rows (max 64)", span, ring);
 	/* Strip width: a multiple of 16 pixels makes every row store start and end on a 64-byte
 	 * boundary (no memory line is shared by two waves' stores; measured 6 % faster than the
 	 * widest width that fits, 248); other widths only if no such width fits. */
@@ -349,31 +369,34 @@ static bool plan_roll(const FixcaGeom *g, unsigned flags, FixcaPlan *pl)
 	/* the width search walks every column for every candidate width and does not depend on the
 	 * row range: remembered per thread, so that a caller working through an image in row bands
 	 * (fixca_region_host's pipeline, the preview) plans each band in microseconds */
-	static thread_local struct { bool valid; FixcaGeom g; int oc_env; int oc_pick; } memo;
+	static thread_local struct { bool valid; FixcaGeom g; int oc_env; int oc_pick; int edge; } memo;
 	FixcaGeom key = *g;
 	key.y1 = key.y2 = 0;
 	key.preview = 0;
-	int oc_pick = 0;
+	int oc_pick = 0, edge = 0;
 	if (memo.valid && memo.oc_env == oc_env && memcmp(&memo.g, &key, sizeof key) == 0) {
 		oc_pick = memo.oc_pick;
+		edge = memo.edge;
 	} else {
 		if (oc_env) {
 			for (int oc = oc_env; oc >= 128 && !oc_pick; oc -= 4)
-				if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+				if (roll_cols_fit(g, oc, taps, &edge)) oc_pick = oc;
 		} else {
 			for (int oc = oc_top & ~15; oc >= 128 && !oc_pick; oc -= 16)
-				if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+				if (roll_cols_fit(g, oc, taps, &edge)) oc_pick = oc;
 			for (int oc = oc_top; oc >= 128 && !oc_pick; oc -= 4)
-				if (roll_cols_fit(g, oc, taps)) oc_pick = oc;
+				if (roll_cols_fit(g, oc, taps, &edge)) oc_pick = oc;
 		}
 		memo.valid = true;
 		memo.g = key;
 		memo.oc_env = oc_env;
 		memo.oc_pick = oc_pick;
+		memo.edge = edge;
 	}
 	for (int oc = oc_pick; oc >= 128; oc = 0) {
 		const int rows = g->y2 - g->y1;
 		pl->kernel = FIXCA_K_ROLL;
+		pl->edge = edge;
 		pl->oc = oc;
 		pl->ring = ring;
 		pl->nstrips = (g->W + oc - 1) / oc;
@@ -1024,8 +1047,9 @@ void fixca_plan_text(const FixcaGeom *g, const FixcaPlan *pl, char *buf, size_t 
 		         pl->oc, pl->th, pl->ring, pl->nu, pl->depth, pl->nstrips, pl->nchunks, pl->nwaves,
 		         (pl->kernel == FIXCA_K_LIN && pl->wide_fast) ? " weights+recheck" : "");
 	else if (pl->kernel == FIXCA_K_SCAN || pl->kernel == FIXCA_K_ROLL)
-		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d", kn[pl->kernel],
-		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves);
+		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d ring=%d strips=%d chunks=%d waves=%d%s", kn[pl->kernel],
+		         in[g->interp], g->bpp, pl->oc, pl->th, pl->ring, pl->nstrips, pl->nchunks, pl->nwaves,
+		         (pl->kernel == FIXCA_K_ROLL && pl->edge) ? " edge-pixels" : "");
 	else
 		snprintf(buf, n, "%s %s bpp=%d oc=%d th=%d strips=%d chunks=%d waves=%d blocks=%d", kn[pl->kernel],
 		         in[g->interp], g->bpp, pl->oc, pl->th, pl->nstrips, pl->nchunks, pl->nwaves, pl->nblocks);

@@ -75,7 +75,8 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define RING_ROW    (ROLL_WIN * ROLL_BPP)   /* bytes per ring row                                  */
 
 namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
-#define RING_PAD_LO 16                  /* a lane window may start up to 4 px before a ring row  */
+#define RING_PAD_LO 64                  /* a lane window may start up to 16 px before a ring row (the strips at the image's edges: roll_edge_px) */
+#define ROLL_COLW_CHUNKS 11             /* 16-byte chunks of column constants per lane in the tables: 10 of weights, 1 of flags */
 #define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
 #ifndef ROLL_NRB
 #define ROLL_NRB    4                   /* output rows per block of the regular path.  2 (135 instead of 166 VGPRs for RGB8
@@ -153,7 +154,7 @@ __device__ __forceinline__ float next_lane_ubyte2(uint32_t v)
 #define ROLL_EXP_END(st, dst, lane, gen) do { } while (0)
 #endif
 
-template <int TAPS, bool P2, bool ODD>  /* P2: the ring has a power-of-two number of rows; ODD: see roll_tile */
+template <int TAPS, bool P2, int ODD>  /* P2: the ring has a power-of-two number of rows; ODD: see roll_tile */
 struct RollState {
 	ROLL_EXP_FIELDS
 	static constexpr int T = TAPS;
@@ -182,6 +183,9 @@ struct RollState {
 	uint32_t strip_bytes;       /* bytes of an output row this wave stores */
 	uint32_t dst_bytes;         /* size of the output descriptor: the offset that makes a store a no-op */
 	int      edge_wb;           /* RollSched::edge_wb (scalar) */
+	uint32_t fmask;             /* ODD == 2: my flagged edge pixels (roll_edge_px): bit 2i + c: output i, channel c takes the row's first pixel, bit 8 + 2i + c: its last */
+	int      edge;              /* ODD == 2, scalar: 1: some lane of the strip has a flagged first-pixel output, 2: last-pixel (never both: the planner) */
+	uint32_t edge_off;          /* ODD == 2, scalar: byte offset in a ring row of that pixel */
 	int      part;              /* width not a multiple of 4: pixels (1..3) of the strip's last, partial lane; 0 = none (scalar) */
 	uint32_t vo_part;           /* ... that lane's byte offset inside an output row; past the end in every other lane */
 	bool     idt_al;            /* my_idt is a multiple of 16 bytes (RGB8: of 4) (always, unless the window was pushed back from the right edge of such an image) */
@@ -190,14 +194,14 @@ struct RollState {
 };
 
 /* ring slot of source row `row` (row >= 0): row mod K */
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ int roll_slot(const RollState<TAPS, P2, ODD> &st, int row)
 {
 	if constexpr (P2) return row & st.KM;
 	else return row - (st.KM + 1) * (int)__umulhi((uint32_t)row, st.kmagic);
 }
 
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ void roll_issue(RollState<TAPS, P2, ODD> &st)
 {
 	++st.ld;
@@ -235,7 +239,7 @@ __device__ __forceinline__ void roll_issue(RollState<TAPS, P2, ODD> &st)
  * rows' loads are younger than the one needed, and "at most ld - need operations outstanding" implies "at most
  * ld - need loads outstanding", which implies the needed row is in LDS.  Stores in flight make
  * the wait stricter, never wrong. */
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2, ODD> &st, int keep, int need)
 {
 	const int target = min(min(need + RDEPTH, keep + st.KM), st.lastneed);
@@ -255,7 +259,7 @@ __device__ __forceinline__ void roll_fetch(RollState<TAPS, P2, ODD> &st, int kee
  * (RGBA) or 12 bytes at a 4-byte aligned offset (RGB; .w unused) */
 struct __attribute__((packed, aligned(4))) RollPx4 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(4))) RollPx3 { uint32_t a, b, c; };
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2, ODD> &st, int row, uint32_t off)
 {
 #if ROLL_BPP == 4
@@ -287,7 +291,7 @@ __device__ __forceinline__ u32x4 roll_ring_px(const RollState<TAPS, P2, ODD> &st
  * the access is left to the compiler as 4-byte aligned: two ds_read2_b32.
  * RGB: 12 bytes at ANY byte address (3 bytes per pixel): the 16 bytes around them are read from the dword
  * boundary below (st.tap is that boundary); the bytes are picked out where they are converted. */
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ u32x4 roll_ring_win(const RollState<TAPS, P2, ODD> &st, int row, int off)
 {
 	const RollPx4 v = *reinterpret_cast<const RollPx4 *>(st.ring + roll_slot(st, row) * RING_ROW + off);
@@ -350,7 +354,7 @@ __device__ __forceinline__ void rgb_cvt(int r, const u32x4 (&p)[NR], f32x2 (&tp)
 /* the 8 (NP used) pixels of the windows of NR source rows per channel, as (red, blue) floats.
  * pr / pb: my 4 pixels; with the 272-column window every lane has also read the next 4 (nr / nb),
  * with the 256-column window they come from lane L + 1 over DPP. */
-template <int TAPS, bool P2, bool ODD, int NR, int NP>
+template <int TAPS, bool P2, int ODD, int NR, int NP>
 __device__ __forceinline__ void roll_px8(const RollState<TAPS, P2, ODD> &st, const u32x4 (&pr)[NR], const u32x4 (&pb)[NR],
                                          const u32x4 (&nr)[NR], const u32x4 (&nb)[NR], f32x2 (&tp)[NR][NP])
 {
@@ -376,7 +380,7 @@ __device__ __forceinline__ void roll_px8(const RollState<TAPS, P2, ODD> &st, con
 }
 
 /* the pixels after my 4-pixel tap window (272-column window only; a dummy otherwise) */
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2, ODD> &st, int row, int off)
 {
 #if ROLL_NEXT_FROM_LDS
@@ -386,9 +390,68 @@ __device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2, ODD> &
 #endif
 }
 
+/* Edge pixels.  An output whose source coordinate falls outside the image is the row's first or last pixel, whatever
+ * the lens does to its neighbours (the coordinate is clamped: fix-ca.c:799-819).  In the strips at the image's left and
+ * right edge such outputs sit next to outputs whose taps are 5 and more columns away, out of reach of the 5 window
+ * pixels an output has: until round 4 that sent every 6000-pixel image with an amount of about -4 and beyond to the scan
+ * kernel (27 % of the HBM peak instead of 70 %).  Now the tables give such an output the weight 1 on the FIRST (left
+ * edge) or LAST (right edge) of its 5 window pixels and flag it in the lane's 11th chunk, and the kernel overwrites
+ * that window pixel with the row's first / last pixel, read from the ring as a broadcast.  The map is monotone, so the
+ * flagged outputs are the lane's first (last) ones and the overwritten pixel is no tap of the lane's other outputs.
+ * Only in the instantiations ODD == 2 (the launcher picks them when the planner found such a strip: FixcaPlan.edge), and
+ * there in the tiles of such strips only (EDGE: their own copy of the row loop); an edge output the 5 pixels do reach
+ * is filtered like any other. */
+/* the row's edge pixel: red from ring row rowR, blue from rowB, as raw bytes.  In roll_block these reads go with the
+ * window reads, BEFORE the block refills the ring slots it has read. */
+template <int TAPS, bool P2, int ODD, int NR>
+__device__ __forceinline__ void roll_edge_read(const RollState<TAPS, P2, ODD> &st, int rowR, int rowB, uint32_t (&e)[NR][2])
+{
+#pragma unroll
+	for (int n = 0; n < NR; ++n) {
+		int r0 = rowR + n, r1 = rowB + n;
+		asm volatile("" : "+v"(r0), "+v"(r1));         /* the addresses in vector registers: the kernel has no scalar register to spare */
+		e[n][0] = st.ring[roll_slot(st, r0) * RING_ROW + st.edge_off];
+		e[n][1] = st.ring[roll_slot(st, r1) * RING_ROW + st.edge_off + 2];
+	}
+}
+template <int TAPS, bool P2, int ODD, int NR, int NP>
+__device__ __forceinline__ void roll_edge_px(const RollState<TAPS, P2, ODD> &st, const uint32_t (&e)[NR][2], f32x2 (&tp)[NR][NP])
+{
+	/* Selected with v_bfe_i32 (0 / ~0 of a flag) + v_bfi_b32, written out: left to the compiler the 16 flag tests become
+	 * 16 lane masks in scalar register pairs, computed once per tile, and 40 to 100 other scalars of the kernel spill
+	 * (700 v_readlane in the cubic instantiation). */
+	const uint32_t fm = st.fmask;
+	auto pick = [&](float cur, float ev, auto bit) {
+		uint32_t k;
+		asm volatile("v_bfe_i32 %1, %3, %4, 1\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(cur), "=&v"(k) : "v"(ev), "v"(fm), "n"(decltype(bit)::value));
+		return cur;
+	};
+#pragma unroll
+	for (int n = 0; n < NR; ++n) {
+		const float eR = (float)e[n][0], eB = (float)e[n][1];
+		if (st.edge & 1) {
+#define EDGE_L(I) \
+			if constexpr (NP > (I)) { \
+				tp[n][I].x = pick(tp[n][I].x, eR, std::integral_constant<int, 2 * (I)>{}); \
+				tp[n][I].y = pick(tp[n][I].y, eB, std::integral_constant<int, 2 * (I) + 1>{}); \
+			}
+			EDGE_L(0) EDGE_L(1) EDGE_L(2) EDGE_L(3)
+#undef EDGE_L
+		} else {
+#define EDGE_R(I) \
+			if constexpr (NP > (I) + 4) { \
+				tp[n][(I) + 4].x = pick(tp[n][(I) + 4].x, eR, std::integral_constant<int, 8 + 2 * (I)>{}); \
+				tp[n][(I) + 4].y = pick(tp[n][(I) + 4].y, eB, std::integral_constant<int, 9 + 2 * (I)>{}); \
+			}
+			EDGE_R(0) EDGE_R(1) EDGE_R(2) EDGE_R(3)
+#undef EDGE_R
+		}
+	}
+}
+
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
  * h[i] = sum_t wx[i][t] * px8[i + t] for my 4 output columns */
-template <int TAPS, bool P2, bool ODD, int NW>
+template <int TAPS, bool P2, int ODD, int NW, bool EDGE = false>
 __device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5],
                                           int rowR, int rowB, f32x2 (&h)[4])
 {
@@ -396,6 +459,11 @@ __device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2, ODD> &st, co
 	const u32x4 pb[1] = { roll_ring_win(st, rowB, st.tap[1]) }, nb[1] = { roll_ring_next(st, rowB, st.tap[1]) };
 	f32x2 tp[1][NW + 3];
 	roll_px8<TAPS, P2, ODD, 1, NW + 3>(st, pr, pb, nr, nb, tp);
+	if constexpr (EDGE) {
+		uint32_t ed[1][2];
+		roll_edge_read<TAPS, P2, ODD, 1>(st, rowR, rowB, ed);
+		roll_edge_px<TAPS, P2, ODD, 1, NW + 3>(st, ed, tp);
+	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		f32x2 a = wx[i][0] * tp[0][i];
@@ -447,7 +515,7 @@ __device__ __forceinline__ void roll_wy_rows(cfloat_p roww, int y, f32x2 (&wy)[N
 #endif
 
 /* saturating round-to-nearest conversion straight into the red and blue bytes, then the row store */
-template <int TAPS, bool P2, bool ODD>
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ void roll_store(RollState<TAPS, P2, ODD> &st, const f32x2 (&acc)[4], const u32x4 &idt)
 {
 	/* The row offset is added into the vector offset on purpose.  With the row offset in the
@@ -521,7 +589,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2, ODD> &st, const f
 
 /* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
  * window touches the top or bottom edge: edge rows replicate, fix-ca.c:1218-1256) */
-template <int TAPS, bool P2, bool ODD, int NW>
+template <int TAPS, bool P2, int ODD, int NW, bool EDGE = false>
 __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                              cfloat_p roww, int y)
 {
@@ -531,7 +599,7 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const
 	f32x2 rows[T][4];
 #pragma unroll
 	for (int t = 0; t < T; ++t)
-		roll_hrow<TAPS, P2, ODD, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
+		roll_hrow<TAPS, P2, ODD, NW, EDGE>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
 	f32x2 v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
@@ -552,7 +620,7 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const
  * All ring reads of the rows are issued together; the filter arithmetic is written tap-major
  * (for each tap, all rows and outputs) so that consecutive instructions belong to different
  * accumulation chains. */
-template <int TAPS, bool P2, bool ODD, int NW, int NR>
+template <int TAPS, bool P2, int ODD, int NW, int NR, bool EDGE = false>
 __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                            const RollBlock &bn, cfloat_p roww, int y)
 {
@@ -572,6 +640,8 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f
 		nb[n] = roll_ring_next(st, nB + n, st.tap[1]);
 		idt[n] = roll_ring_px(st, y + n, st.my_idt);
 	}
+	[[maybe_unused]] uint32_t ed[NR][2];
+	if constexpr (EDGE) roll_edge_read<TAPS, P2, ODD, NR>(st, nR, nB, ed);
 	f32x2 acc[NR][4], wy[NR][T];
 	roll_wy_rows<TAPS, NR>(roww, y, wy);
 	/* Everything this block needs from the ring is now in registers (after the wait), so the
@@ -597,6 +667,7 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
 	roll_px8<TAPS, P2, ODD, NR, NP>(st, pr, pb, nr, nb, tp);
+	if constexpr (EDGE) roll_edge_px<TAPS, P2, ODD, NR, NP>(st, ed, tp);
 #pragma unroll
 	for (int t = 0; t < NW; ++t)
 #pragma unroll
@@ -637,12 +708,13 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f
 }
 
 /* one tile: output rows [Y0, Y0 + nrows) of strip `strip` of image `img`.
- * ODD: the tile may end in a lane of 1-3 pixels, or read its own pixels from a ring offset that is not lane-aligned: the
+ * ODD != 0: the tile may end in a lane of 1-3 pixels, or read its own pixels from a ring offset that is not lane-aligned: the
  * last strips of an image whose width is not a multiple of 4.  Such images run their own instantiation of the kernel
  * (wave-uniform branches per row in every strip); for all others the code is compiled out: as scalar branches in the one
  * kernel it cost the single-image launch 1.2 points (RGB8: 2.1), as a second variant inside the one kernel 0.7 (1.9:
- * scalar registers spilled). */
-template <int TAPS, bool P2, bool ODD>
+ * scalar registers spilled).  ODD == 2: that, and strips with edge pixels out of their lane windows' reach
+ * (roll_edge_px). */
+template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ void
 roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPlan &pl, const RollTables &tb,
           int img, int strip, int Y0, int nrows, int edge_wb)
@@ -696,7 +768,8 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	const int nfull = wcols >> 2;                    /* ... of which these store 4 pixels */
 	f32x2 wx[4][5];
 	{
-		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
+		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (ROLL_COLW_CHUNKS * 64) + lane;
+		if constexpr (ODD == 2) st.fmask = __builtin_bit_cast(uint32_t, cw[10 * 64].x);
 		float f[40];
 #pragma unroll
 		for (int q = 0; q < 10; ++q) {
@@ -730,18 +803,26 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	st.part = wcols & 3;
 	st.vo_part = (st.part && lane == nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
 	st.idt_al = ((X0 - U0) & 3) == 0;
+	if constexpr (ODD == 2) {
+		st.edge = hd.gen >> 1;                            /* scalar: the strip header comes from scalar loads */
+		st.edge_off = (uint32_t)(((st.edge & 1) ? 0 : W - 1) - U0) * ROLL_BPP;   /* read only by strips whose window holds the pixel (the planner checks: roll_cols_fit) */
+	}
 	st.row_phase = (uint32_t)(uintptr_t)dst + (uint32_t)Y0 * st.pitch + (uint32_t)X0 * ROLL_BPP;      /* mod 2^32: only the low bits are used */
 	st.strip_bytes = (uint32_t)wcols * ROLL_BPP;
 	st.dst_bytes = dst_bytes;
 	st.edge_wb = edge_wb;
 
-	auto run = [&](auto nw_tag) {
+	auto run = [&](auto nw_tag, auto edge_tag) {
 		constexpr int NW = decltype(nw_tag)::value;
+		constexpr bool EDGE = decltype(edge_tag)::value;
 		int r = 0;
 		while (r < nrows) {
 			const int y = Y0 + r;
 			constexpr int NRB = ROLL_NRB, RMASK = (1 << NRB) - 1;
-			const bool four = r > 0 && r + NRB - 1 < nrows && (b.reg4 & RMASK) == RMASK;
+			/* strips with edge pixels go row by row: with 4 rows' windows converted before the overwrite the kernel would need
+			 * 181 registers instead of 142, for every strip of the image (2 waves per SIMD instead of 3: 50 % of the HBM peak
+			 * where this form reaches 6x: profiles/r04_edge_pixels.txt) */
+			const bool four = !EDGE && r > 0 && r + NRB - 1 < nrows && (b.reg4 & RMASK) == RMASK;
 			const bool one = r > 0 && (b.reg4 & 1);      /* tails and rows next to an irregular one */
 			const int step = four ? NRB : 1;
 			/* the next descriptor is requested before this block's work: its scalar load has the
@@ -749,15 +830,23 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 			RollBlock bn = b;
 			if (r + step < nrows) bn = load_block(blocks, y + step);
 			if (four)     roll_block<TAPS, P2, ODD, NW, NRB>(st, wx, b, bn, roww, y);
-			else if (one) roll_block<TAPS, P2, ODD, NW, 1>(st, wx, b, bn, roww, y);
-			else          roll_row_any<TAPS, P2, ODD, NW>(st, wx, b, roww, y);
+			else if (one) roll_block<TAPS, P2, ODD, NW, 1, EDGE>(st, wx, b, bn, roww, y);
+			else          roll_row_any<TAPS, P2, ODD, NW, EDGE>(st, wx, b, roww, y);
 			r += step;
 			b = bn;
 		}
 	};
 	STAMP(5);                                       /* prologue */
-	if (hd.gen) run(std::integral_constant<int, 5>{});
-	else        run(std::integral_constant<int, (T == 1) ? 2 : T>{});
+	if constexpr (ODD == 2) {
+		if (st.edge != 0) {
+			if (hd.gen & 1) run(std::integral_constant<int, 5>{}, std::true_type{});
+			else            run(std::integral_constant<int, (T == 1) ? 2 : T>{}, std::true_type{});
+			ROLL_EXP_END(st, dst, lane, (unsigned long long)hd.gen | ((unsigned long long)strip << 8) | ((unsigned long long)Y0 << 20));
+			return;
+		}
+	}
+	if (hd.gen & 1) run(std::integral_constant<int, 5>{}, std::false_type{});
+	else            run(std::integral_constant<int, (T == 1) ? 2 : T>{}, std::false_type{});
 	ROLL_EXP_END(st, dst, lane, (unsigned long long)hd.gen | ((unsigned long long)strip << 8) | ((unsigned long long)Y0 << 20));
 }
 
@@ -767,7 +856,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 #else
 #define ROLL_OCC
 #endif
-template <int TAPS, bool P2, bool ODD>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC; ODD: the image's width is not a multiple of 4 */
+template <int TAPS, bool P2, int ODD>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC; ODD: 1 the image's width is not a multiple of 4, 2 that or edge pixels (roll_edge_px) */
 __global__ __launch_bounds__(64) ROLL_OCC void
 k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 {
@@ -872,17 +961,26 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 	int   col[2][4][T];
 	float wt[2][4][T];
 	int   mlo[2] = { 1 << 30, 1 << 30 };             /* min over the strip of (tap column - x), taps with weight */
+	int   mall[2] = { 1 << 30, 1 << 30 }, mhi[2] = { -(1 << 30), -(1 << 30) };   /* min and max of the same, edge pixels included */
+	int   ecol[2][4];                                /* all of the output's weight is on this edge column (-1: it is not): see roll_edge_px */
+	auto edge_column = [&](int c, int i, int column) {
+		ecol[c][i] = (column == 0 || column == W - 1) ? column : -1;
+		return ecol[c][i] >= 0;
+	};
 #pragma unroll
 	for (int c = 0; c < 2; ++c)
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
+			ecol[c][i] = -1;
 			const int x = min(xl + i, W - 1);            /* a partial last lane: its outputs past the image repeat the last column's taps and are never stored */
 			if constexpr (T == 1) {
 				/* NONE: one "tap" of weight 1 on the rounded source column (fix-ca.c:799-809);
 				 * the 0/1 weights make the fp32 filter below an exact byte gather */
 				col[c][i][0] = map_int(x, g.xc, W, g.s[c], g.xs[c]);
 				wt[c][i][0] = 1.0f;
-				mlo[c] = min(mlo[c], col[c][i][0] - x);
+				if (!edge_column(c, i, col[c][i][0])) mlo[c] = min(mlo[c], col[c][i][0] - x);
+				mall[c] = min(mall[c], col[c][i][0] - x);
+				mhi[c] = max(mhi[c], col[c][i][0] - x);
 			} else {
 				const double xd = map_dbl(x, g.xc, W, g.s[c], g.xs[c]);
 				const int x0 = (int)floor(xd);
@@ -904,8 +1002,12 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 				constexpr int CT = (T == 4) ? 1 : 0;                    /* the tap with weight 1 at fraction 0 */
 				if (fx != 0.0) {
 					mlo[c] = min(mlo[c], col[c][i][0] - x);
+					mall[c] = min(mall[c], col[c][i][0] - x);
+					mhi[c] = max(mhi[c], col[c][i][T - 1] - x);
 				} else {
-					mlo[c] = min(mlo[c], col[c][i][CT] - x);
+					mall[c] = min(mall[c], col[c][i][CT] - x);
+					mhi[c] = max(mhi[c], col[c][i][CT] - x);
+					if (!edge_column(c, i, col[c][i][CT])) mlo[c] = min(mlo[c], col[c][i][CT] - x);
 #pragma unroll
 					for (int t = 0; t < T; ++t) wt[c][i][t] = (t == CT) ? 1.0f : 0.0f;
 				}
@@ -915,8 +1017,28 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 #pragma unroll
 	for (int c = 0; c < 2; ++c) {
 #pragma unroll
-		for (int m = 32; m >= 1; m >>= 1) mlo[c] = min(mlo[c], __shfl_xor(mlo[c], m, 64));
+		for (int m = 32; m >= 1; m >>= 1) {
+			mlo[c] = min(mlo[c], __shfl_xor(mlo[c], m, 64));
+			mall[c] = min(mall[c], __shfl_xor(mall[c], m, 64));
+			mhi[c] = max(mhi[c], __shfl_xor(mhi[c], m, 64));
+		}
 		mlo[c] = __builtin_amdgcn_readfirstlane(mlo[c]);
+		mall[c] = __builtin_amdgcn_readfirstlane(mall[c]);
+		mhi[c] = __builtin_amdgcn_readfirstlane(mhi[c]);
+		if (mlo[c] == (1 << 30)) mlo[c] = 0;             /* every output of the strip is an edge pixel */
+	}
+	/* While the 5 window pixels reach every tap of the strip, edge pixels are outputs like any others.  Otherwise the
+	 * window follows the other outputs, and the edge pixels it does not reach are flagged: bit 2i + c first pixel, bit
+	 * 8 + 2i + c last pixel (the planner takes the same decisions: roll_cols_fit) */
+	uint32_t fmask = 0;
+#pragma unroll
+	for (int c = 0; c < 2; ++c) {
+		if (mhi[c] - mall[c] <= 4) { mlo[c] = mall[c]; continue; }
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int j = ecol[c][i] - (xl + i) - mlo[c];    /* as the fold below places it */
+			if (ecol[c][i] >= 0 && (j < 0 || j > 4)) fmask |= (ecol[c][i] == 0 ? 1u : 0x100u) << (2 * i + c);
+		}
 	}
 
 	/* fold steps and clamped taps into 5 weights per output: pixel i + j of the lane's 8 has column
@@ -930,10 +1052,15 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 		for (int jj = 0; jj < 5; ++jj) {
 			float a[2] = { 0.f, 0.f };
 #pragma unroll
-			for (int c = 0; c < 2; ++c)
+			for (int c = 0; c < 2; ++c) {
+				if (fmask & (0x101u << (2 * i + c))) {       /* a flagged edge pixel: weight 1 on the window pixel k_roll overwrites */
+					a[c] = (jj == ((fmask & (1u << (2 * i + c))) ? 0 : 4)) ? 1.f : 0.f;
+					continue;
+				}
 #pragma unroll
 				for (int t = 0; t < T; ++t)
 					a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
+			}
 			wx[i][jj][0] = a[0];
 			wx[i][jj][1] = a[1];
 			if (jj >= ((T == 1) ? 2 : T)) gen = gen || (a[0] != 0.f) || (a[1] != 0.f);
@@ -942,7 +1069,9 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 
 	/* lane weights: 40 floats in the order (i, jj, channel), as 10 chunks of 16 bytes, chunk q of
 	 * all 64 lanes contiguous */
-	f32x4 *cw = reinterpret_cast<f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
+	f32x4 *cw = reinterpret_cast<f32x4 *>(tb.colw) + (size_t)strip * (ROLL_COLW_CHUNKS * 64) + lane;
+	cw[10 * 64] = f32x4{ __builtin_bit_cast(float, fmask), 0.f, 0.f, 0.f };
+	const bool edge_l = __any((fmask & 0xffu) != 0 && active) != 0, edge_r = __any((fmask & 0xff00u) != 0 && active) != 0;
 #pragma unroll
 	for (int q = 0; q < 10; ++q) {
 		float f[4];
@@ -958,7 +1087,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 		h.U0 = U0;
 		h.tapR = X0 + mlo[0] - U0;
 		h.tapB = X0 + mlo[1] - U0;
-		h.gen = gen ? 1 : 0;
+		h.gen = (gen ? 1 : 0) | (edge_l ? 2 : 0) | (edge_r ? 4 : 0);     /* bit 0: the 5-weight path; bits 1, 2: flagged edge pixels */
 		tb.strips[strip] = h;
 	}
 }
@@ -1121,7 +1250,7 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	}
 	const size_t n_strips = (size_t)pl->nstrips;
 	const size_t off_colw = (n_strips * sizeof(RollStrip) + 255) & ~(size_t)255;
-	const size_t off_blocks = off_colw + n_strips * 10 * 64 * 16;
+	const size_t off_blocks = off_colw + n_strips * ROLL_COLW_CHUNKS * 64 * 16;
 	const size_t off_roww = off_blocks + (size_t)g->H * sizeof(RollBlock);
 	const size_t need = off_roww + (size_t)g->H * 8 * sizeof(float);
 	if (need > t.bytes || t.device != dev) {
@@ -1187,14 +1316,16 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 	const dim3 grid((unsigned)sc.pool_blocks * (unsigned)n_images);
 	auto launch = [&](auto taps_tag, auto p2_tag, auto odd_tag) -> hipError_t {
 		constexpr int TP = decltype(taps_tag)::value;
-		constexpr bool P2 = decltype(p2_tag)::value, OD = decltype(odd_tag)::value;
+		constexpr bool P2 = decltype(p2_tag)::value;
+		constexpr int OD = decltype(odd_tag)::value;
 		hipError_t ea = (hipError_t)fixca_dyn_lds((const void *)k_roll<TP, P2, OD>, 96 * 1024);
 		if (ea != hipSuccess) return ea;
 		hipLaunchKernelGGL((k_roll<TP, P2, OD>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
 		return hipGetLastError();
 	};
 	auto by_odd = [&](auto taps_tag, auto p2_tag) -> hipError_t {
-		return odd ? launch(taps_tag, p2_tag, std::true_type{}) : launch(taps_tag, p2_tag, std::false_type{});
+		return pl->edge ? launch(taps_tag, p2_tag, std::integral_constant<int, 2>{})
+		     : odd      ? launch(taps_tag, p2_tag, std::integral_constant<int, 1>{}) : launch(taps_tag, p2_tag, std::integral_constant<int, 0>{});
 	};
 	auto by_p2 = [&](auto taps_tag) -> hipError_t {
 		return p2 ? by_odd(taps_tag, std::true_type{}) : by_odd(taps_tag, std::false_type{});

@@ -121,6 +121,14 @@ def test_planner_choices():
     k, desc = fixca.plan(6002, 4000, 3, 1, cub)                         # width not a multiple of 4: the main kernel since round 4 (rows at byte addresses)
     assert k == 6 and "roll cubic bpp=3" in desc
     assert fixca.plan(257, 193, 4, 1, cub)[0] == 6                      # ... RGBA8 too (a last lane of one pixel)
+    # amounts of about -4 and beyond: outputs clamped to the row's first / last pixel lie out of their neighbours' 5 window
+    # pixels' reach: the main kernel overwrites them (scan / register-window kernels until round 4)
+    assert "edge-pixels" not in desc and "edge-pixels" not in fixca.plan(6000, 4000, 4, 1, cub)[1]
+    for bpp in (4, 3):
+        for interp in (0, 1, 2):
+            for blue, red in ((5, -5), (-6, -6), (12, -12), (-4, 9)):
+                k, desc = fixca.plan(6000, 4000, bpp, 1, fixca.make_params(blue=blue, red=red, lens_x=658, lens_y=1280, interpolation=interp))
+                assert k == 6 and ("edge-pixels" in desc or (blue, red) == (-4, 9)), (bpp, interp, blue, red, desc)
     k, desc = fixca.plan(255, 193, 4, 1, cub)                           # narrower than the 256-column window: register-window kernel
     assert k == 3 and "fast-interp cubic" in desc
     assert fixca.plan(6000, 4000, 4, 1, cub, kernel=fixca.KERNEL_EXACT)[0] == 1

@@ -256,6 +256,46 @@ def test_rgb8_widths_that_are_not_multiples_of_4(torch_cuda, w, interp):
         assert (out[:y1] == 0x3C).all() and (out[y2:] == 0x3C).all()
 
 
+EDGE_PIXEL_PARAMS = [
+    dict(blue=6.0, red=-6.0),                                     # clamped on the left and right for red, none for blue
+    dict(blue=-5.0, red=-5.0),
+    dict(blue=-12.0, red=8.0, lens_x=0.25, lens_y=0.7),
+    dict(blue=-4.0, red=4.0, x_blue=-7.0, x_red=6.5),             # lateral shifts on top: one side only per channel
+    dict(x_blue=-11.0, x_red=13.0, y_blue=2.0),                   # no scaling: every column shifts alike
+    dict(blue=-15.0, red=-9.5, lens_x=0.9, lens_y=0.1),
+]
+
+
+@pytest.mark.parametrize("shape", [(1200, 97, 4), (1200, 97, 3), (1003, 61, 4), (1001, 61, 3), (256, 40, 4), (481, 50, 3), (4500, 45, 4)], ids=str)
+@pytest.mark.parametrize("pi", range(len(EDGE_PIXEL_PARAMS)))
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_edge_pixels_beyond_the_window(torch_cuda, shape, pi, interp):
+    """Outputs whose coordinate is clamped to the image are the row's first / last pixel.  With amounts of about -4 and
+    beyond they lie next to outputs whose taps are further away than a lane's 5 window pixels reach; until round 4 such
+    images left the main 8-bit kernel (27 % of the HBM peak instead of 70 %).  The kernel now overwrites those window
+    pixels with the edge pixel (fixca_roll.hip, roll_edge_px).  Single and batch entry against the oracle."""
+    torch = torch_cuda
+    w, h, c = shape
+    p = fixca.make_params(interpolation=interp, **_scaled(dict(dict(lens_x=0.5, lens_y=0.5), **EDGE_PIXEL_PARAMS[pi]), w, h))
+    kid, desc = fixca.plan(w, h, c, 1, p)
+    if pi == 0 and w >= (4000 if interp == 2 else 1000):    # (CUBIC at 1200 columns: +-6 changes the shift by 2.4 pixels across a strip, more than 5 window pixels hold)
+        assert kid == 6 and "edge-pixels" in desc, desc
+    tol = 0 if interp == 0 else TOL_LSB
+    imgs = [synth.noise_image(0xED6E + 7 * w + i, w, h, c) for i in range(2)]
+    refs = [oracle_run(a, p) for a in imgs]
+    out = gpu_run(torch, imgs[0], p, fixca.KERNEL_AUTO)
+    mx, _ = diff_stats(out, refs[0])
+    assert mx <= tol, desc
+    assert np.array_equal(out[..., 1], imgs[0][..., 1])
+    srcs = [torch.from_numpy(a).cuda() for a in imgs]
+    dsts = [torch.full_like(s, 0x5A) for s in srcs]
+    fixca.fix_ca_batch(srcs, dsts, w, h, c, 1, p)
+    torch.cuda.synchronize()
+    for d_, r_ in zip(dsts, refs):
+        mx, _ = diff_stats(d_.cpu().numpy(), r_)
+        assert mx <= tol, desc
+
+
 # ---- shapes and edges -------------------------------------------------------------
 
 SHAPES = [(8, 1, 4), (8, 5, 3), (9, 9, 3), (11, 7, 4), (64, 40, 4), (253, 33, 3), (255, 65, 4), (256, 64, 4),

@@ -6,7 +6,7 @@ planner / table caches; they share the HIP runtime), the source and result image
 variants are timed in rotation, `--rounds` times.  Prints per variant the per-round percentages of the HBM peak
 (8 TB/s over 2 x bytes per image) and their median, and checks once that every variant computes HEAD's pixels.
 
-    python tools/ab.py [--bpp 4] [--bpc 1] [--interp 2] [--images 128] [--rounds 4] [--single] VARIANT ...
+    python tools/ab.py [--bpp 4] [--bpc 1] [--interp 2] [--images 128] [--rounds 4] [--single] [--blue 2 --red -2] VARIANT ...
 
     VARIANT = name[@lib][,ENV=value ...][,per=N]
         lib   directory under tools/bin/ holding a libfixca_hip.so built by tools/build_variant.sh (default: the
@@ -32,6 +32,8 @@ ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--width", type=int, default=6000)
 ap.add_argument("--height", type=int, default=4000)
+ap.add_argument("--blue", type=float, default=2.0, help="lateral amounts (the headline workload: blue 2, red -2)")
+ap.add_argument("--red", type=float, default=-2.0)
 ap.add_argument("--single", action="store_true", help="one image per launch through fixca_region_device")
 ap.add_argument("--grid", default="", help="cartesian product of variants: 'lib=HEAD,d10;FIXCA_TH=0,64,160;per=8' (0 / HEAD = unset / in-tree library)")
 ap.add_argument("variants", nargs="*")
@@ -83,7 +85,7 @@ def lib_for(path):
         libs[path] = l
     return libs[path]
 
-p = fixca.make_params(blue=2.0, red=-2.0, lens_x=658, lens_y=1280, interpolation=a.interp)
+p = fixca.make_params(blue=a.blue, red=a.red, lens_x=658, lens_y=1280, interpolation=a.interp)
 src = torch.empty((N, H, W, PB), dtype=torch.uint8, device="cuda")
 for i in range(N):
     fixca.noise_fill(src[i], 0xF1CAA000 + i)
