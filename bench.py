@@ -76,6 +76,10 @@ CONFIGS = [
     dict(name="RGBA8 cubic, 5999 wide, lens (658,1280), 5999x4000", w=5999, h=4000, c=4, bpc=1, params=PARAMS),
     dict(name="RGB8 cubic, 5999 wide, lens (658,1280), 5999x4000", w=5999, h=4000, c=3, bpc=1, params=PARAMS),
     dict(name="RGB u16 cubic, 5999 wide, lens (658,1280), 5999x4000", w=5999, h=4000, c=3, bpc=2, params=PARAMS, images=64),
+    # stronger corrections (outputs clamped to the row's edge pixels lie out of a lane window's reach): the main kernel's
+    # edge-pixel instantiation since round 4, before that k_scan (44 %) / k_interp (22 %)
+    dict(name="RGBA8 cubic, blue 5 red -5, lens (658,1280), 6000x4000", w=6000, h=4000, c=4, bpc=1, params=dict(PARAMS, blue=5.0, red=-5.0)),
+    dict(name="RGB8 cubic, blue 5 red -5, lens (658,1280), 6000x4000", w=6000, h=4000, c=3, bpc=1, params=dict(PARAMS, blue=5.0, red=-5.0)),
 ]
 
 
@@ -186,14 +190,13 @@ KID_CUB = 10                     # ... of the LDS-ring CUBIC kernel of the wide 
 
 def kernel_name(kid, plan_text, width=0):
     """the device function a plan runs, from the planner's own description (width: the image's, for the row-rolling
-    kernel's third template argument: 1 = its instantiation for widths that are not multiples of 4, 2 = the one that also
-    overwrites edge pixels)"""
+    kernel's third template argument: 1 = its instantiation for widths that are not multiples of 4)"""
     words = plan_text.split()
     if kid == KID_ROLL:
         taps = {"none": 1, "linear": 2, "cubic": 4}[words[1]]
         ring = int([w for w in words if w.startswith("ring=")][0][5:])
         rgb = "bpp=3" in words
-        return "k_roll%s<%d,%s,%d>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false", 2 if "edge-pixels" in words else 1 if width % 4 else 0)
+        return "k_roll%s<%d,%s,%d>" % ("_rgb" if rgb else "", taps, "true" if ring & (ring - 1) == 0 else "false", 1 if width % 4 else 0)
     return {"exact-fp64": "k_exact/k_wide", "fast-none": "k_none", "fast-interp": "k_interp", "scan": "k_scan", "scanw": "k_scanw",
             "wide-roll-fp64": "k_wcol", "move-none": "k_move", "ring-linear-fp64": "k_lin", "ring-cubic-fp64": "k_cub"}.get(words[0], words[0])
 

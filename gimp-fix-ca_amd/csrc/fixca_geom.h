@@ -40,7 +40,7 @@ struct FixcaPlan {
 	int wide_fast;      /* 16-bit samples, kernel 7 (CUBIC, fixca_wide.hip) and kernel 9 (LINEAR, fixca_lin.hip): the weight form with
 	                       exact recomputation of the samples near a rounding boundary; 0 = operation for operation */
 	int edge;           /* kernel 6: some strip has outputs that are the row's first / last pixel beyond the reach of their 5
-	                       window pixels: the instantiation that overwrites them (fixca_roll.hip, roll_edge_px) */
+	                       window pixels: rewritten at the end of each tile (fixca_roll.hip, roll_edge_pixels); informative */
 };
 
 #define FIXCA_K_EXACT   1

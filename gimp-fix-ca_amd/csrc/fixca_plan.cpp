@@ -289,9 +289,9 @@ static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int
  * start at most 16 px before and end at most 16 px past the 256-column ring row (the pads);
  * every column that carries weight is inside the ring row.
  * Outputs that ARE the row's first or last pixel (a coordinate clamped to the image: all the weight on column 0 or
- * W - 1) do not count towards m and the 5-pixel reach: the ones the 5 pixels do not reach are overwritten by the
- * kernel (fixca_roll.hip, roll_edge_px; k_roll_tables takes the same decisions on the same fp64 values) and make the
- * plan one for the instantiation that does so (*edge). */
+ * W - 1) do not count towards m and the 5-pixel reach: the ones the 5 pixels do not reach are rewritten at the end of
+ * each tile (fixca_roll.hip, roll_edge_pixels; k_roll_tables takes the same decisions on the same fp64 values): they
+ * must be the strip's first or last outputs, of one side only, at most 255 per channel (*edge: the plan has some). */
 static int roll_win(const FixcaGeom *g) { return g->bpp == 3 ? ROLL_WIN_RGB : ROLL_WIN; }
 
 static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps, int *edge)
@@ -325,13 +325,22 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps, int *edge)
 			if (mx_all - mn_all <= 4) { m[c] = mn_all; continue; }      /* the 5 pixels reach everything: edge pixels are outputs like any others */
 			if (mn == INT_MAX) mn = mx = 0;                              /* a strip of edge pixels only */
 			if (mx - mn > 4) PLAN_REFUSE("roll oc=%d strip %d channel %d: tap offsets span %d..%d (more than 5 lane pixels)", oc, st, c, mn, mx);
+			int nfl = 0, fl_lo = INT_MAX, fl_hi = INT_MIN;
 			for (int x = X0; x < xe; ++x) {
 				int f, l;
 				tap_span(g, c, x, taps, &f, &l);
 				if (!(f == l && (f == 0 || f == W - 1))) continue;
-				if (f - x - mn < 0 || f - x - mn > 4) { *edge = 1; sides |= (f == 0) ? 1 : 2; }
+				if (f - x - mn < 0 || f - x - mn > 4) {
+					*edge = 1;
+					sides |= (f == 0) ? 1 : 2;
+					++nfl;
+					if (x < fl_lo) fl_lo = x;
+					if (x > fl_hi) fl_hi = x;
+				}
 			}
-			if (sides == 3) PLAN_REFUSE("roll oc=%d strip %d: edge pixels of both sides", oc, st);    /* the kernel reads one edge pixel per row and strip */
+			if (sides == 3) PLAN_REFUSE("roll oc=%d strip %d: edge pixels of both sides", oc, st);    /* the tile's last step rewrites one side */
+			if (nfl > 255 || (nfl && sides == 1 && (fl_lo != 0 || fl_hi != nfl - 1)) || (nfl && sides == 2 && (fl_hi != W - 1 || fl_lo != W - nfl)))
+				PLAN_REFUSE("roll oc=%d strip %d channel %d: %d edge pixels in columns %d..%d are not the row's first / last", oc, st, c, nfl, fl_lo, fl_hi);
 			m[c] = mn;
 		}
 		int U0 = lo & ~ROLL_U0_MASK;

@@ -41,8 +41,9 @@
 struct RollStrip {
 	int U0;             /* first column of the 256-column source window (multiple of 4)          */
 	int tapR, tapB;     /* pixel offset, in a ring row, of lane 0's 4-pixel tap window (may be < 0) */
-	int gen;            /* bit 0: some output of the strip needs the 5th weight (step or image edge); bits 1, 2: some output
-	                       is a flagged first / last pixel of the row (fixca_roll.hip, roll_edge_px) */
+	int gen;            /* bit 0: some output of the strip needs the 5th weight (step or image edge); bit 1 / bit 2: the strip's
+	                       first / last outputs are edge pixels out of their window's reach (fixca_roll.hip, roll_edge_pixels):
+	                       bits 8-15 how many for red, bits 16-23 for blue */
 };
 
 /* one output row y, seen as the first row of a block (32 bytes) */
@@ -57,7 +58,7 @@ struct RollBlock {
 
 struct RollTables {
 	RollStrip *strips;  /* [nstrips]                                                               */
-	float     *colw;    /* [nstrips][11][64 lanes][4]: a lane's 5 x 4 (red, blue) tap weights, then its edge-pixel flags */
+	float     *colw;    /* [nstrips][10][64 lanes][4]: a lane's 5 x 4 (red, blue) tap weights        */
 	RollBlock *blocks;  /* [H]                                                                     */
 	float     *roww;    /* [H][8]: (red, blue) vertical weights of tap 0..3                          */
 };

@@ -75,8 +75,7 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define RING_ROW    (ROLL_WIN * ROLL_BPP)   /* bytes per ring row                                  */
 
 namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
-#define RING_PAD_LO 64                  /* a lane window may start up to 16 px before a ring row (the strips at the image's edges: roll_edge_px) */
-#define ROLL_COLW_CHUNKS 11             /* 16-byte chunks of column constants per lane in the tables: 10 of weights, 1 of flags */
+#define RING_PAD_LO 64                  /* a lane window may start up to 16 px before a ring row (the strips at the image's edges: roll_edge_pixels) */
 #define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
 #ifndef ROLL_NRB
 #define ROLL_NRB    4                   /* output rows per block of the regular path.  2 (135 instead of 166 VGPRs for RGB8
@@ -183,9 +182,6 @@ struct RollState {
 	uint32_t strip_bytes;       /* bytes of an output row this wave stores */
 	uint32_t dst_bytes;         /* size of the output descriptor: the offset that makes a store a no-op */
 	int      edge_wb;           /* RollSched::edge_wb (scalar) */
-	uint32_t fmask;             /* ODD == 2: my flagged edge pixels (roll_edge_px): bit 2i + c: output i, channel c takes the row's first pixel, bit 8 + 2i + c: its last */
-	int      edge;              /* ODD == 2, scalar: 1: some lane of the strip has a flagged first-pixel output, 2: last-pixel (never both: the planner) */
-	uint32_t edge_off;          /* ODD == 2, scalar: byte offset in a ring row of that pixel */
 	int      part;              /* width not a multiple of 4: pixels (1..3) of the strip's last, partial lane; 0 = none (scalar) */
 	uint32_t vo_part;           /* ... that lane's byte offset inside an output row; past the end in every other lane */
 	bool     idt_al;            /* my_idt is a multiple of 16 bytes (RGB8: of 4) (always, unless the window was pushed back from the right edge of such an image) */
@@ -390,68 +386,9 @@ __device__ __forceinline__ u32x4 roll_ring_next(const RollState<TAPS, P2, ODD> &
 #endif
 }
 
-/* Edge pixels.  An output whose source coordinate falls outside the image is the row's first or last pixel, whatever
- * the lens does to its neighbours (the coordinate is clamped: fix-ca.c:799-819).  In the strips at the image's left and
- * right edge such outputs sit next to outputs whose taps are 5 and more columns away, out of reach of the 5 window
- * pixels an output has: until round 4 that sent every 6000-pixel image with an amount of about -4 and beyond to the scan
- * kernel (27 % of the HBM peak instead of 70 %).  Now the tables give such an output the weight 1 on the FIRST (left
- * edge) or LAST (right edge) of its 5 window pixels and flag it in the lane's 11th chunk, and the kernel overwrites
- * that window pixel with the row's first / last pixel, read from the ring as a broadcast.  The map is monotone, so the
- * flagged outputs are the lane's first (last) ones and the overwritten pixel is no tap of the lane's other outputs.
- * Only in the instantiations ODD == 2 (the launcher picks them when the planner found such a strip: FixcaPlan.edge), and
- * there in the tiles of such strips only (EDGE: their own copy of the row loop); an edge output the 5 pixels do reach
- * is filtered like any other. */
-/* the row's edge pixel: red from ring row rowR, blue from rowB, as raw bytes.  In roll_block these reads go with the
- * window reads, BEFORE the block refills the ring slots it has read. */
-template <int TAPS, bool P2, int ODD, int NR>
-__device__ __forceinline__ void roll_edge_read(const RollState<TAPS, P2, ODD> &st, int rowR, int rowB, uint32_t (&e)[NR][2])
-{
-#pragma unroll
-	for (int n = 0; n < NR; ++n) {
-		int r0 = rowR + n, r1 = rowB + n;
-		asm volatile("" : "+v"(r0), "+v"(r1));         /* the addresses in vector registers: the kernel has no scalar register to spare */
-		e[n][0] = st.ring[roll_slot(st, r0) * RING_ROW + st.edge_off];
-		e[n][1] = st.ring[roll_slot(st, r1) * RING_ROW + st.edge_off + 2];
-	}
-}
-template <int TAPS, bool P2, int ODD, int NR, int NP>
-__device__ __forceinline__ void roll_edge_px(const RollState<TAPS, P2, ODD> &st, const uint32_t (&e)[NR][2], f32x2 (&tp)[NR][NP])
-{
-	/* Selected with v_bfe_i32 (0 / ~0 of a flag) + v_bfi_b32, written out: left to the compiler the 16 flag tests become
-	 * 16 lane masks in scalar register pairs, computed once per tile, and 40 to 100 other scalars of the kernel spill
-	 * (700 v_readlane in the cubic instantiation). */
-	const uint32_t fm = st.fmask;
-	auto pick = [&](float cur, float ev, auto bit) {
-		uint32_t k;
-		asm volatile("v_bfe_i32 %1, %3, %4, 1\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(cur), "=&v"(k) : "v"(ev), "v"(fm), "n"(decltype(bit)::value));
-		return cur;
-	};
-#pragma unroll
-	for (int n = 0; n < NR; ++n) {
-		const float eR = (float)e[n][0], eB = (float)e[n][1];
-		if (st.edge & 1) {
-#define EDGE_L(I) \
-			if constexpr (NP > (I)) { \
-				tp[n][I].x = pick(tp[n][I].x, eR, std::integral_constant<int, 2 * (I)>{}); \
-				tp[n][I].y = pick(tp[n][I].y, eB, std::integral_constant<int, 2 * (I) + 1>{}); \
-			}
-			EDGE_L(0) EDGE_L(1) EDGE_L(2) EDGE_L(3)
-#undef EDGE_L
-		} else {
-#define EDGE_R(I) \
-			if constexpr (NP > (I) + 4) { \
-				tp[n][(I) + 4].x = pick(tp[n][(I) + 4].x, eR, std::integral_constant<int, 8 + 2 * (I)>{}); \
-				tp[n][(I) + 4].y = pick(tp[n][(I) + 4].y, eB, std::integral_constant<int, 9 + 2 * (I)>{}); \
-			}
-			EDGE_R(0) EDGE_R(1) EDGE_R(2) EDGE_R(3)
-#undef EDGE_R
-		}
-	}
-}
-
 /* horizontal filter of one source row per channel (red from ring row rowR, blue from rowB):
  * h[i] = sum_t wx[i][t] * px8[i + t] for my 4 output columns */
-template <int TAPS, bool P2, int ODD, int NW, bool EDGE = false>
+template <int TAPS, bool P2, int ODD, int NW>
 __device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5],
                                           int rowR, int rowB, f32x2 (&h)[4])
 {
@@ -459,11 +396,6 @@ __device__ __forceinline__ void roll_hrow(const RollState<TAPS, P2, ODD> &st, co
 	const u32x4 pb[1] = { roll_ring_win(st, rowB, st.tap[1]) }, nb[1] = { roll_ring_next(st, rowB, st.tap[1]) };
 	f32x2 tp[1][NW + 3];
 	roll_px8<TAPS, P2, ODD, 1, NW + 3>(st, pr, pb, nr, nb, tp);
-	if constexpr (EDGE) {
-		uint32_t ed[1][2];
-		roll_edge_read<TAPS, P2, ODD, 1>(st, rowR, rowB, ed);
-		roll_edge_px<TAPS, P2, ODD, 1, NW + 3>(st, ed, tp);
-	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		f32x2 a = wx[i][0] * tp[0][i];
@@ -550,7 +482,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2, ODD> &st, const f
 	} else
 #endif
 	__builtin_amdgcn_raw_buffer_store_b128(out, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
-	if (ODD && st.part != 0) {
+	if ((ODD) && st.part != 0) {
 		/* the image's last 1-3 columns: one lane, as many dwords (a 16-byte store would run into the next row) */
 		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 		typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
@@ -572,7 +504,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2, ODD> &st, const f
 	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].x, 1, o2);
 	o2 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].y, 3, o2);
 	__builtin_amdgcn_raw_buffer_store_b96(u32x3{ o0, o1, o2 }, st.rs_dst, st.vo_st + st.so_st, 0, ROLL_ST_AUX);
-	if (ODD && st.part != 0) {
+	if ((ODD) && st.part != 0) {
 		/* the image's last 1-3 columns (a width that is not a multiple of 4): one lane, 3 / 6 / 9 bytes, byte by byte
 		 * (a 12-byte store would run into the next row) */
 		const uint32_t off = st.vo_part + st.so_st;
@@ -589,7 +521,7 @@ __device__ __forceinline__ void roll_store(RollState<TAPS, P2, ODD> &st, const f
 
 /* one output row, windows rebuilt from the ring (first row of a wave, scale steps, rows whose
  * window touches the top or bottom edge: edge rows replicate, fix-ca.c:1218-1256) */
-template <int TAPS, bool P2, int ODD, int NW, bool EDGE = false>
+template <int TAPS, bool P2, int ODD, int NW>
 __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                              cfloat_p roww, int y)
 {
@@ -599,7 +531,7 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const
 	f32x2 rows[T][4];
 #pragma unroll
 	for (int t = 0; t < T; ++t)
-		roll_hrow<TAPS, P2, ODD, NW, EDGE>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
+		roll_hrow<TAPS, P2, ODD, NW>(st, wx, rclampi(b.rb[0] + t, 0, st.H - 1), rclampi(b.rb[1] + t, 0, st.H - 1), rows[t]);
 	f32x2 v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = f32x2{ ROUND_BIAS, ROUND_BIAS };
@@ -620,7 +552,7 @@ __device__ __forceinline__ void roll_row_any(RollState<TAPS, P2, ODD> &st, const
  * All ring reads of the rows are issued together; the filter arithmetic is written tap-major
  * (for each tap, all rows and outputs) so that consecutive instructions belong to different
  * accumulation chains. */
-template <int TAPS, bool P2, int ODD, int NW, int NR, bool EDGE = false>
+template <int TAPS, bool P2, int ODD, int NW, int NR>
 __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f32x2 (&wx)[4][5], const RollBlock &b,
                                            const RollBlock &bn, cfloat_p roww, int y)
 {
@@ -640,8 +572,6 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f
 		nb[n] = roll_ring_next(st, nB + n, st.tap[1]);
 		idt[n] = roll_ring_px(st, y + n, st.my_idt);
 	}
-	[[maybe_unused]] uint32_t ed[NR][2];
-	if constexpr (EDGE) roll_edge_read<TAPS, P2, ODD, NR>(st, nR, nB, ed);
 	f32x2 acc[NR][4], wy[NR][T];
 	roll_wy_rows<TAPS, NR>(roww, y, wy);
 	/* Everything this block needs from the ring is now in registers (after the wait), so the
@@ -667,7 +597,6 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f
 	/* horizontal: rows[T-1+n][i] = sum_t wx[i][t] * px8[n][i + t] */
 	f32x2 tp[NR][NP];
 	roll_px8<TAPS, P2, ODD, NR, NP>(st, pr, pb, nr, nb, tp);
-	if constexpr (EDGE) roll_edge_px<TAPS, P2, ODD, NR, NP>(st, ed, tp);
 #pragma unroll
 	for (int t = 0; t < NW; ++t)
 #pragma unroll
@@ -707,13 +636,56 @@ __device__ __forceinline__ void roll_block(RollState<TAPS, P2, ODD> &st, const f
 	STAMP(4);                                       /* conversions + stores */
 }
 
+/* Edge pixels.  An output whose source coordinate falls outside the image is the row's first or last pixel, whatever
+ * the lens does to its neighbours (the coordinate is clamped: fix-ca.c:799-819).  In the strips at the image's left and
+ * right edge such outputs sit next to outputs whose taps are 5 and more columns away, out of reach of the 5 window
+ * pixels an output has: until round 4 that sent every 6000-pixel image with an amount of about -4 and beyond to the scan
+ * kernel (44 .. 27 % of the HBM peak instead of 70 %).  Now the tables give such an output no weight at all (and leave it
+ * out of the strip's tap offsets), the row loop stores whatever that makes of it, and the wave that owns the tile
+ * rewrites those samples when its rows are done: lane k takes row Y0 + k (+ 64, ...), filters the edge column's T
+ * samples with the row's vertical weights, in the row loop's own arithmetic, and stores the byte n times, for the strip's
+ * n such outputs per channel (the first n of a row, or the last n: the map is monotone; the planner checks).  A few
+ * hundred byte accesses per tile, in 2 strips of 25, after a wait for the tile's own stores (the order of two stores of
+ * one wave to one address).  An edge output the 5 window pixels do reach is an output like any other.
+ * Other forms tried: the window pixel overwritten inside the row loop, as a third instantiation of the kernel, 50 % (181
+ * registers); the same in a row-by-row copy of the loop for the edge strips, 68.6 % in a launch of many images but 28 %
+ * in a launch of one, where the slow edge tiles are the launch's tail (profiles/r04_edge_pixels.txt). */
+template <int TAPS>
+__device__ __forceinline__ void roll_edge_pixels(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const FixcaGeom &g,
+                                              const RollTables &tb, int gen, int Y0, int nrows, int lane)
+{
+	constexpr int T = TAPS;
+	const int W = g.W, H = g.H;
+	const size_t pitch = (size_t)W * ROLL_BPP;
+	const int n[2] = { (gen >> 8) & 0xff, (gen >> 16) & 0xff };
+	const int ecol = (gen & 2) ? 0 : W - 1;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* the tile's own stores of these bytes first */
+	for (int r = lane; r < nrows; r += 64) {
+		const int y = Y0 + r;
+		const RollBlock b = tb.blocks[y];
+		const float *wy = tb.roww + (size_t)y * 8;
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			if (n[c] == 0) continue;
+			float acc = ROUND_BIAS;
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
+				const int row = rclampi(b.rb[c] + t, 0, H - 1);
+				acc = __builtin_fmaf(wy[2 * t + c], (float)src[(size_t)row * pitch + (size_t)ecol * ROLL_BPP + 2 * c], acc);
+			}
+			const uint8_t v = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(acc, 0, 0u);
+			uint8_t *o = dst + (size_t)y * pitch + (size_t)((gen & 2) ? 0 : W - n[c]) * ROLL_BPP + 2 * c;
+			for (int k = 0; k < n[c]; ++k) o[(size_t)k * ROLL_BPP] = v;
+		}
+	}
+}
+
 /* one tile: output rows [Y0, Y0 + nrows) of strip `strip` of image `img`.
- * ODD != 0: the tile may end in a lane of 1-3 pixels, or read its own pixels from a ring offset that is not lane-aligned: the
+ * ODD: the tile may end in a lane of 1-3 pixels, or read its own pixels from a ring offset that is not lane-aligned: the
  * last strips of an image whose width is not a multiple of 4.  Such images run their own instantiation of the kernel
  * (wave-uniform branches per row in every strip); for all others the code is compiled out: as scalar branches in the one
  * kernel it cost the single-image launch 1.2 points (RGB8: 2.1), as a second variant inside the one kernel 0.7 (1.9:
- * scalar registers spilled).  ODD == 2: that, and strips with edge pixels out of their lane windows' reach
- * (roll_edge_px). */
+ * scalar registers spilled). */
 template <int TAPS, bool P2, int ODD>
 __device__ __forceinline__ void
 roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPlan &pl, const RollTables &tb,
@@ -753,6 +725,11 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	                                              (uint32_t)(st.lastneed - b.keep + 1) * st.pitch, 0x00020000);
 	st.rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)Y0 * st.pitch, 0, dst_bytes, 0x00020000);
 
+	/* what the tile's last step needs (roll_edge_pixels), parked in vector registers: the row loop has no scalar
+	 * register to spare (kept in scalars these five spilled three others in the cubic kernel) */
+	uint32_t park[5] = { (uint32_t)(uintptr_t)src, (uint32_t)((uintptr_t)src >> 32), (uint32_t)(uintptr_t)dst, (uint32_t)((uintptr_t)dst >> 32), (uint32_t)hd.gen };
+	asm volatile("" : "+v"(park[0]), "+v"(park[1]), "+v"(park[2]), "+v"(park[3]), "+v"(park[4]));
+
 	/* start filling the ring before anything else */
 	st.ld = b.keep - 1;
 	st.vo_ld = (ROLL_BPP == 4) ? (uint32_t)(U0 + 4 * lane) * 4u : (uint32_t)U0 * 3u + 16u * (uint32_t)lane;
@@ -768,8 +745,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	const int nfull = wcols >> 2;                    /* ... of which these store 4 pixels */
 	f32x2 wx[4][5];
 	{
-		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (ROLL_COLW_CHUNKS * 64) + lane;
-		if constexpr (ODD == 2) st.fmask = __builtin_bit_cast(uint32_t, cw[10 * 64].x);
+		const f32x4 *cw = reinterpret_cast<const f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
 		float f[40];
 #pragma unroll
 		for (int q = 0; q < 10; ++q) {
@@ -803,26 +779,18 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 	st.part = wcols & 3;
 	st.vo_part = (st.part && lane == nfull) ? (uint32_t)(X0 + 4 * lane) * ROLL_BPP : dst_bytes;
 	st.idt_al = ((X0 - U0) & 3) == 0;
-	if constexpr (ODD == 2) {
-		st.edge = hd.gen >> 1;                            /* scalar: the strip header comes from scalar loads */
-		st.edge_off = (uint32_t)(((st.edge & 1) ? 0 : W - 1) - U0) * ROLL_BPP;   /* read only by strips whose window holds the pixel (the planner checks: roll_cols_fit) */
-	}
 	st.row_phase = (uint32_t)(uintptr_t)dst + (uint32_t)Y0 * st.pitch + (uint32_t)X0 * ROLL_BPP;      /* mod 2^32: only the low bits are used */
 	st.strip_bytes = (uint32_t)wcols * ROLL_BPP;
 	st.dst_bytes = dst_bytes;
 	st.edge_wb = edge_wb;
 
-	auto run = [&](auto nw_tag, auto edge_tag) {
+	auto run = [&](auto nw_tag) {
 		constexpr int NW = decltype(nw_tag)::value;
-		constexpr bool EDGE = decltype(edge_tag)::value;
 		int r = 0;
 		while (r < nrows) {
 			const int y = Y0 + r;
 			constexpr int NRB = ROLL_NRB, RMASK = (1 << NRB) - 1;
-			/* strips with edge pixels go row by row: with 4 rows' windows converted before the overwrite the kernel would need
-			 * 181 registers instead of 142, for every strip of the image (2 waves per SIMD instead of 3: 50 % of the HBM peak
-			 * where this form reaches 6x: profiles/r04_edge_pixels.txt) */
-			const bool four = !EDGE && r > 0 && r + NRB - 1 < nrows && (b.reg4 & RMASK) == RMASK;
+			const bool four = r > 0 && r + NRB - 1 < nrows && (b.reg4 & RMASK) == RMASK;
 			const bool one = r > 0 && (b.reg4 & 1);      /* tails and rows next to an irregular one */
 			const int step = four ? NRB : 1;
 			/* the next descriptor is requested before this block's work: its scalar load has the
@@ -830,23 +798,24 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 			RollBlock bn = b;
 			if (r + step < nrows) bn = load_block(blocks, y + step);
 			if (four)     roll_block<TAPS, P2, ODD, NW, NRB>(st, wx, b, bn, roww, y);
-			else if (one) roll_block<TAPS, P2, ODD, NW, 1, EDGE>(st, wx, b, bn, roww, y);
-			else          roll_row_any<TAPS, P2, ODD, NW, EDGE>(st, wx, b, roww, y);
+			else if (one) roll_block<TAPS, P2, ODD, NW, 1>(st, wx, b, bn, roww, y);
+			else          roll_row_any<TAPS, P2, ODD, NW>(st, wx, b, roww, y);
 			r += step;
 			b = bn;
 		}
 	};
 	STAMP(5);                                       /* prologue */
-	if constexpr (ODD == 2) {
-		if (st.edge != 0) {
-			if (hd.gen & 1) run(std::integral_constant<int, 5>{}, std::true_type{});
-			else            run(std::integral_constant<int, (T == 1) ? 2 : T>{}, std::true_type{});
-			ROLL_EXP_END(st, dst, lane, (unsigned long long)hd.gen | ((unsigned long long)strip << 8) | ((unsigned long long)Y0 << 20));
-			return;
-		}
+	if (hd.gen & 1) run(std::integral_constant<int, 5>{});
+	else            run(std::integral_constant<int, (T == 1) ? 2 : T>{});
+	const int gen_end = __builtin_amdgcn_readfirstlane((int)park[4]);
+	if (__builtin_expect((gen_end & 6) != 0, 0)) {
+		auto addr = [&](uint32_t lo, uint32_t hi) {      /* (readfirstlane returns int: through uint32_t, or a low word with bit 31 set sign-extends into the high one) */
+			return (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo) | ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32);
+		};
+		const uint8_t *s_end = reinterpret_cast<const uint8_t *>(addr(park[0], park[1]));
+		uint8_t *d_end = reinterpret_cast<uint8_t *>(addr(park[2], park[3]));
+		roll_edge_pixels<TAPS>(s_end, d_end, g, tb, gen_end, Y0, nrows, lane);
 	}
-	if (hd.gen & 1) run(std::integral_constant<int, 5>{}, std::false_type{});
-	else            run(std::integral_constant<int, (T == 1) ? 2 : T>{}, std::false_type{});
 	ROLL_EXP_END(st, dst, lane, (unsigned long long)hd.gen | ((unsigned long long)strip << 8) | ((unsigned long long)Y0 << 20));
 }
 
@@ -856,7 +825,7 @@ roll_tile(uint8_t *lds, const RollBatch &imgs, const FixcaGeom &g, const FixcaPl
 #else
 #define ROLL_OCC
 #endif
-template <int TAPS, bool P2, int ODD>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC; ODD: 1 the image's width is not a multiple of 4, 2 that or edge pixels (roll_edge_px) */
+template <int TAPS, bool P2, int ODD>   /* TAPS: 1 = NONE (a 1-tap filter with weights 0/1: exact), 2 = LINEAR, 4 = CUBIC; ODD: 1 = the image's width is not a multiple of 4 */
 __global__ __launch_bounds__(64) ROLL_OCC void
 k_roll(RollBatch imgs, FixcaGeom g, FixcaPlan pl, RollTables tb, RollSched sc)
 {
@@ -1053,10 +1022,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 			float a[2] = { 0.f, 0.f };
 #pragma unroll
 			for (int c = 0; c < 2; ++c) {
-				if (fmask & (0x101u << (2 * i + c))) {       /* a flagged edge pixel: weight 1 on the window pixel k_roll overwrites */
-					a[c] = (jj == ((fmask & (1u << (2 * i + c))) ? 0 : 4)) ? 1.f : 0.f;
-					continue;
-				}
+				if (fmask & (0x101u << (2 * i + c))) continue;      /* a flagged edge pixel: no weight, rewritten after the tile's rows (roll_edge_pixels) */
 #pragma unroll
 				for (int t = 0; t < T; ++t)
 					a[c] += (col[c][i][t] - (xl + i) - mlo[c] == jj) ? wt[c][i][t] : 0.f;
@@ -1069,9 +1035,17 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 
 	/* lane weights: 40 floats in the order (i, jj, channel), as 10 chunks of 16 bytes, chunk q of
 	 * all 64 lanes contiguous */
-	f32x4 *cw = reinterpret_cast<f32x4 *>(tb.colw) + (size_t)strip * (ROLL_COLW_CHUNKS * 64) + lane;
-	cw[10 * 64] = f32x4{ __builtin_bit_cast(float, fmask), 0.f, 0.f, 0.f };
+	f32x4 *cw = reinterpret_cast<f32x4 *>(tb.colw) + (size_t)strip * (10 * 64) + lane;
 	const bool edge_l = __any((fmask & 0xffu) != 0 && active) != 0, edge_r = __any((fmask & 0xff00u) != 0 && active) != 0;
+	int nflag[2];                                    /* flagged outputs of the strip per channel (those inside the image) */
+#pragma unroll
+	for (int c = 0; c < 2; ++c) {
+		nflag[c] = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) nflag[c] += (active && xl + i < W && (fmask & (0x101u << (2 * i + c)))) ? 1 : 0;
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) nflag[c] += __shfl_xor(nflag[c], m, 64);
+	}
 #pragma unroll
 	for (int q = 0; q < 10; ++q) {
 		float f[4];
@@ -1087,7 +1061,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 		h.U0 = U0;
 		h.tapR = X0 + mlo[0] - U0;
 		h.tapB = X0 + mlo[1] - U0;
-		h.gen = (gen ? 1 : 0) | (edge_l ? 2 : 0) | (edge_r ? 4 : 0);     /* bit 0: the 5-weight path; bits 1, 2: flagged edge pixels */
+		h.gen = (gen ? 1 : 0) | (edge_l ? 2 : 0) | (edge_r ? 4 : 0) | (nflag[0] << 8) | (nflag[1] << 16);   /* see RollStrip */
 		tb.strips[strip] = h;
 	}
 }
@@ -1250,7 +1224,7 @@ static hipError_t ensure_tables(const FixcaGeom *g, const FixcaPlan *pl, hipStre
 	}
 	const size_t n_strips = (size_t)pl->nstrips;
 	const size_t off_colw = (n_strips * sizeof(RollStrip) + 255) & ~(size_t)255;
-	const size_t off_blocks = off_colw + n_strips * ROLL_COLW_CHUNKS * 64 * 16;
+	const size_t off_blocks = off_colw + n_strips * 10 * 64 * 16;
 	const size_t off_roww = off_blocks + (size_t)g->H * sizeof(RollBlock);
 	const size_t need = off_roww + (size_t)g->H * 8 * sizeof(float);
 	if (need > t.bytes || t.device != dev) {
@@ -1324,8 +1298,7 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 		return hipGetLastError();
 	};
 	auto by_odd = [&](auto taps_tag, auto p2_tag) -> hipError_t {
-		return pl->edge ? launch(taps_tag, p2_tag, std::integral_constant<int, 2>{})
-		     : odd      ? launch(taps_tag, p2_tag, std::integral_constant<int, 1>{}) : launch(taps_tag, p2_tag, std::integral_constant<int, 0>{});
+		return odd ? launch(taps_tag, p2_tag, std::integral_constant<int, 1>{}) : launch(taps_tag, p2_tag, std::integral_constant<int, 0>{});
 	};
 	auto by_p2 = [&](auto taps_tag) -> hipError_t {
 		return p2 ? by_odd(taps_tag, std::true_type{}) : by_odd(taps_tag, std::false_type{});
