@@ -286,7 +286,7 @@ static void tap_span(const FixcaGeom *g, int c, int x, int taps, int *first, int
 
 /* Every strip must satisfy what k_roll assumes: with m = min over the strip of (tap column - x),
  * every tap with weight lands on pixel i + j of the lane's 8, 0 <= j <= 4; the lane windows
- * start at most 16 px before and end at most 16 px past the 256-column ring row (the pads);
+ * start at most 32 px before and end at most 32 px past the 256-column ring row (the pads: 128 bytes each);
  * every column that carries weight is inside the ring row.
  * Outputs that ARE the row's first or last pixel (a coordinate clamped to the image: all the weight on column 0 or
  * W - 1) do not count towards m and the 5-pixel reach: the ones the 5 pixels do not reach are rewritten at the end of
@@ -349,7 +349,7 @@ static bool roll_cols_fit(const FixcaGeom *g, int oc, int taps, int *edge)
 		const int nact = (xe - X0 + 3) >> 2;            /* producing lanes (the last may be partial); lane `nact` is read as a neighbour */
 		for (int c = 0; c < 2; ++c) {
 			const int P = X0 + m[c] - U0;
-			if (P < -16 || P + 4 * nact + 4 > WIN + 16) PLAN_REFUSE("roll oc=%d strip %d channel %d: lane windows start at %d (pads allow -16 .. %d)", oc, st, c, P, WIN + 16 - 4 * nact - 4);
+			if (P < -32 || P + 4 * nact + 4 > WIN + 32) PLAN_REFUSE("roll oc=%d strip %d channel %d: lane windows start at %d (pads allow -32 .. %d)", oc, st, c, P, WIN + 32 - 4 * nact - 4);
 		}
 	}
 	return true;

@@ -75,8 +75,8 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define RING_ROW    (ROLL_WIN * ROLL_BPP)   /* bytes per ring row                                  */
 
 namespace ROLL_NAME(fixca_roll_ns) {    /* the two compilations define the same templates differently */
-#define RING_PAD_LO 64                  /* a lane window may start up to 16 px before a ring row (the strips at the image's edges: roll_edge_pixels) */
-#define RING_PAD_HI 64                  /* ... and the last lanes may read 16 px past it         */
+#define RING_PAD_LO 128                 /* a lane window may start up to 32 px before a ring row (the strips at the image's edges: roll_edge_pixels) */
+#define RING_PAD_HI 128                 /* ... and the last lanes may read 32 px past it (the plug-in's amounts go to +-30) */
 #ifndef ROLL_NRB
 #define ROLL_NRB    4                   /* output rows per block of the regular path.  2 (135 instead of 166 VGPRs for RGB8
                                          * cubic) measured 1.5 points slower, 2 with 4 waves per SIMD forced 3.5 points slower */

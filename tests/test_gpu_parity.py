@@ -263,6 +263,8 @@ EDGE_PIXEL_PARAMS = [
     dict(blue=-4.0, red=4.0, x_blue=-7.0, x_red=6.5),             # lateral shifts on top: one side only per channel
     dict(x_blue=-11.0, x_red=13.0, y_blue=2.0),                   # no scaling: every column shifts alike
     dict(blue=-15.0, red=-9.5, lens_x=0.9, lens_y=0.1),
+    dict(blue=25.0, red=-25.0),                                   # lane windows up to 26 pixels off the ring row: the 128-byte pads
+    dict(blue=-22.0, red=-28.0, lens_x=0.4, lens_y=0.6, x_red=3.0),
 ]
 
 
