@@ -1294,6 +1294,32 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 		constexpr int OD = decltype(odd_tag)::value;
 		hipError_t ea = (hipError_t)fixca_dyn_lds((const void *)k_roll<TP, P2, OD>, 96 * 1024);
 		if (ea != hipSuccess) return ea;
+#ifdef ROLL_EXP_SPLIT
+		/* timing experiment (tools/build_variant.sh NAME -DROLL_EXP_SPLIT, never the shipped library): a launch of one image as
+		 * two launches of half its tiles, the second on a stream of its own between a fork and a join event: does the second
+		 * half's start overlap the first half's tail?  (profiles/NOTES.md, round 4 §10) */
+		if (n_images == 1 && (g->y2 - g->y1) >= 4 * sc.th) {
+			static thread_local hipStream_t s2 = nullptr;
+			static thread_local hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+			if (!s2) {
+				if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return hipGetLastError();
+				if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return hipGetLastError();
+				if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return hipGetLastError();
+			}
+			const int chunks = (g->y2 - g->y1 + sc.th - 1) / sc.th;
+			FixcaGeom g1 = *g, g2 = *g;
+			g1.y2 = g2.y1 = g->y1 + ((chunks + 1) / 2) * sc.th;
+			RollSched s1, s2c;
+			roll_make_sched(&g1, pl, 1, &s1);
+			roll_make_sched(&g2, pl, 1, &s2c);
+			s1.th = s2c.th = sc.th;
+			if (hipEventRecord(fork_ev, stream) != hipSuccess || hipStreamWaitEvent(s2, fork_ev, 0) != hipSuccess) return hipGetLastError();
+			hipLaunchKernelGGL((k_roll<TP, P2, OD>), dim3((unsigned)s1.pool_blocks), dim3(64), lds, stream, imgs, g1, *pl, tb, s1);
+			hipLaunchKernelGGL((k_roll<TP, P2, OD>), dim3((unsigned)s2c.pool_blocks), dim3(64), lds, s2, imgs, g2, *pl, tb, s2c);
+			if (hipEventRecord(join_ev, s2) != hipSuccess || hipStreamWaitEvent(stream, join_ev, 0) != hipSuccess) return hipGetLastError();
+			return hipGetLastError();
+		}
+#endif
 		hipLaunchKernelGGL((k_roll<TP, P2, OD>), grid, dim3(64), lds, stream, imgs, *g, *pl, tb, sc);
 		return hipGetLastError();
 	};
