@@ -1284,7 +1284,7 @@ ROLL_NAME(fixca_launch_roll_batch)(const void *const *d_src, void *const *d_dst,
 	if (e != hipSuccess) return e;
 	size_t lds = RING_PAD_LO + (size_t)pl->ring * RING_ROW + RING_PAD_HI;
 	lds += (size_t)fixca_debug_env("FIXCA_EXP_LDS_PAD", 0, 0, 128 * 1024);      /* timing experiment: fewer waves per CU */
-	const bool p2 = (pl->ring & (pl->ring - 1)) == 0, odd = (g->W & 3) != 0;
+	const bool p2 = (pl->ring & (pl->ring - 1)) == 0, odd = (g->W & 3) != 0 || fixca_debug_env("FIXCA_EXP_FORCE_ODD", 0, 0, 1) != 0;   /* (timing experiment: the any-width instantiation on an aligned image) */
 	RollSched sc;
 	roll_make_sched(g, pl, n_images, &sc);
 	const dim3 grid((unsigned)sc.pool_blocks * (unsigned)n_images);
