@@ -733,6 +733,7 @@ def main():
                        "kernel_plan": plan_text},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "recorded (profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, tools/profile.sh), not measured in this run" if traffic else None,
                          "kernel": kernel_name(kid, plan_text, W), "kernel_us": round(kernel_ms * 1e3, 2),
                          "launches_timed": args.steps * launches_per_step,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
