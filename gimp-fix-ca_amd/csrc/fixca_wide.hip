@@ -681,6 +681,9 @@ k_wcol(MoveBatch imgs, FixcaGeom g, WidePlan wp)
 #ifndef WIDE_WEIGHTS_WAVES
 #define WIDE_WEIGHTS_WAVES 3
 #endif
+#ifndef WIDE_WEIGHTS_Q
+#define WIDE_WEIGHTS_Q 2       /* queue slots of the weight form (an A/B build option: deeper queues with 2 waves per SIMD) */
+#endif
 template <typename S, int NCH, int Q, bool ODDW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WIDE_WEIGHTS_WAVES))) void
 k_wcol_weights(MoveBatch imgs, FixcaGeom g, WidePlan wp)
@@ -703,10 +706,10 @@ const void *wcol_kernel(int sel, bool fast)
 	constexpr int Q4 = sizeof(S) == 2 ? WIDE_SLOTS : WIDE_Q_WIDE, Q3 = sizeof(S) == 2 ? WIDE_SLOTS - 1 : WIDE_Q_WIDE;
 	if constexpr (sizeof(S) == 2) {
 		if (fast) switch (sel) {
-		case 11: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, 2, true>);
-		case 10: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, 2, false>);
-		case 9:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, 2, true>);
-		case 8:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, 2, false>);
+		case 11: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, WIDE_WEIGHTS_Q, true>);
+		case 10: return reinterpret_cast<const void *>(&k_wcol_weights<S, 4, WIDE_WEIGHTS_Q, false>);
+		case 9:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, WIDE_WEIGHTS_Q, true>);
+		case 8:  return reinterpret_cast<const void *>(&k_wcol_weights<S, 3, WIDE_WEIGHTS_Q, false>);
 		default: break;
 		}
 	}
