@@ -241,12 +241,12 @@ def time_batch(torch, fixca, srcs, dsts, w, h, bytes_pp, bpc, params, per_launch
     return e0.elapsed_time(e1) * 1e3 / (reps * n)          # us per image
 
 
-CONFIG_POOL_BYTES = 128 * 6000 * 4000 * 4          # the largest pool of a configuration: 12.3 GB of source images (and as many of results)
 
 
 def run_configs(torch, fixca, dev, per_launch, scratch=None):
-    """Every configuration through the same timing.  scratch: two pools' worth of device memory allocated at the START of
-    the process, from which every configuration carves its images.  Memory that torch has freed and allocated again
+    """Every configuration through the same timing.  scratch: (source pool, result pool), device memory allocated at the
+    START of the process from which every configuration carves its images: the timed job's own two image pools, so that a
+    configuration and the headline are measured on the same physical pages.  Memory that torch has freed and allocated again
     reads 3 points slower with this kernel than memory allocated for the first time (tools/alloc_modes2.py,
     profiles/r04_alloc_modes2.txt: 68.7-68.8 against 70.1-71.8 % on the same virtual addresses), and a bench that frees
     its 98-GB pool and then allocates pool after pool measured every configuration in that state (config 3: 69.5 % next
@@ -261,10 +261,10 @@ def run_configs(torch, fixca, dev, per_launch, scratch=None):
         try:
             kid, desc = fixca.plan(w, h, bytes_pp, bpc, p, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)
             pool_bytes = n * h * w * bytes_pp
-            carve = scratch is not None and pool_bytes <= CONFIG_POOL_BYTES
-            raw = make_images(torch, fixca, n, h, w, c, bpc, 0xF1CA2000, dev, into=scratch[:CONFIG_POOL_BYTES] if carve else None)
+            carve = scratch is not None and pool_bytes <= min(scratch[0].numel(), scratch[1].numel())
+            raw = make_images(torch, fixca, n, h, w, c, bpc, 0xF1CA2000, dev, into=scratch[0] if carve else None)
             srcs = [raw[i] for i in range(n)]
-            dstt = scratch[CONFIG_POOL_BYTES:CONFIG_POOL_BYTES + pool_bytes].view(raw.shape) if carve else torch.empty_like(raw)
+            dstt = scratch[1][:pool_bytes].view(raw.shape) if carve else torch.empty_like(raw)
             entry["fresh_memory"] = bool(carve)
             dsts = [dstt[i] for i in range(n)]
             reps = max(4, 1024 // n)             # >= 1024 image passes: short runs read a few percent slow (clock ramp)
@@ -517,10 +517,6 @@ def main():
     params = fdist.broadcast_params(fixca.make_params(**PARAMS) if rank == 0 else None, src=0, device=cdev)
     kid, plan_text = fixca.plan(W, H, C, 1, params, kernel=fixca.KERNEL_AUTO | fixca.PLAN_BATCH)   # what fix_ca_batch will run
 
-    # the configurations' images are carved from memory allocated now, before anything else (run_configs says why)
-    cfg_scratch = None
-    if world == 1 and not args.no_extras and torch.cuda.mem_get_info()[0] > 2 * CONFIG_POOL_BYTES + (200 << 30):
-        cfg_scratch = torch.empty(2 * CONFIG_POOL_BYTES, dtype=torch.uint8, device=dev)
     G = args.batch * world if args.batch else args.global_batch
     if G < world:
         raise SystemExit("bench.py: a batch of %d images cannot give every one of %d ranks an image" % (G, world))
@@ -742,9 +738,12 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_extras:
-            del srcs, dsts, src_all, dst_all, groups
+            # the configurations' images are carved from the timed job's own pools (run_configs says why); nothing below
+            # needs the job's images any more
+            del srcs, dsts, groups
+            out["configs"] = run_configs(torch, fixca, dev, P, (src_all.view(-1), dst_all.view(-1)))
+            del src_all, dst_all
             torch.cuda.empty_cache()
-            out["configs"] = run_configs(torch, fixca, dev, P, cfg_scratch)
         if world == 1 and not args.no_cpu_baseline:
             cb, ref = cpu_baseline(PARAMS, (pv_img, pv_params) if pv_img is not None else None)
             out["cpu_baseline"] = cb
