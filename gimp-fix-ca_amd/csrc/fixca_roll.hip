@@ -931,7 +931,7 @@ k_roll_tables(FixcaGeom g, FixcaPlan pl, RollTables tb)
 	float wt[2][4][T];
 	int   mlo[2] = { 1 << 30, 1 << 30 };             /* min over the strip of (tap column - x), taps with weight */
 	int   mall[2] = { 1 << 30, 1 << 30 }, mhi[2] = { -(1 << 30), -(1 << 30) };   /* min and max of the same, edge pixels included */
-	int   ecol[2][4];                                /* all of the output's weight is on this edge column (-1: it is not): see roll_edge_px */
+	int   ecol[2][4];                                /* all of the output's weight is on this edge column (-1: it is not): see roll_edge_pixels */
 	auto edge_column = [&](int c, int i, int column) {
 		ecol[c][i] = (column == 0 || column == W - 1) ? column : -1;
 		return ecol[c][i] >= 0;

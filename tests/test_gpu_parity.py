@@ -274,8 +274,9 @@ EDGE_PIXEL_PARAMS = [
 def test_edge_pixels_beyond_the_window(torch_cuda, shape, pi, interp):
     """Outputs whose coordinate is clamped to the image are the row's first / last pixel.  With amounts of about -4 and
     beyond they lie next to outputs whose taps are further away than a lane's 5 window pixels reach; until round 4 such
-    images left the main 8-bit kernel (27 % of the HBM peak instead of 70 %).  The kernel now overwrites those window
-    pixels with the edge pixel (fixca_roll.hip, roll_edge_px).  Single and batch entry against the oracle."""
+    images left the main 8-bit kernel (44-27 % of the HBM peak instead of 70 %).  The tables now give them no weight and the
+    wave that owns the tile rewrites them when its rows are done (fixca_roll.hip, roll_edge_pixels).  Single and batch
+    entry against the oracle."""
     torch = torch_cuda
     w, h, c = shape
     p = fixca.make_params(interpolation=interp, **_scaled(dict(dict(lens_x=0.5, lens_y=0.5), **EDGE_PIXEL_PARAMS[pi]), w, h))
