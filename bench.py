@@ -385,6 +385,9 @@ def compact_line(full):
         roof["fp64_kernel_max_abs_diff"] = pf["max_abs_diff"]
     if "second_allocation" in full:
         roof["second_allocation_frac"] = full["second_allocation"]["frac"]
+    if "launch_groups" in full and full["launch_groups"]["frac"]:
+        roof["launch_frac_min"] = min(full["launch_groups"]["frac"])
+        roof["launch_frac_max"] = max(full["launch_groups"]["frac"])
     cfgs = [c for c in full.get("configs", []) if "frac" in c]
     if cfgs:
         rgb8 = [c for c in cfgs if c["name"].startswith("RGB8 cubic")]
@@ -664,6 +667,27 @@ def main():
             elif cc:
                 extra["cold_call_ms"] = cc
             del hsrc, hdst
+            # (4b) the timed job again, launch by launch.  A pool is not uniform: a launch whose sources and results lie in the
+            # same region of device memory runs up to 4 points slower than one whose sources and results lie in different
+            # regions (profiles/NOTES.md, round 4 §12), so the groups of one job differ and `value` is their mix
+            gfr = []
+            for _ in range(2):                                # the device's clocks drop during the host-side legs above: two untimed steps first
+                step()
+            for s_, d_, m in groups:
+                def one():
+                    rc = fixca.lib.fixca_batch_device(s_, d_, m, W, H, C, 1, ctypes.byref(params), fixca.KERNEL_AUTO, stream)
+                    if rc < 0:
+                        raise fixca.FixCaError(rc, fixca.lib.fixca_last_error().decode())
+                one()
+                torch.cuda.synchronize()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(4):
+                    one()
+                g1.record()
+                torch.cuda.synchronize()
+                gfr.append(round(2.0 * C * W * H * m / (g0.elapsed_time(g1) / 4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            extra["launch_groups"] = {"frac": gfr, "what": "the job's launches one by one (4 timed launches each, not the bench value): where a launch's sources and results lie in device memory decides between two modes"}
             # (5) the same job on a second allocation of the image pool.  Which physical pages a buffer lands on decides
             # between two modes of this kernel about 3 points apart (profiles/NOTES.md); `value` is this run's allocation as
             # it came, the second one is context for whoever reads a 69 or a 72 in the line.

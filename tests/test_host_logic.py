@@ -249,14 +249,14 @@ def test_ring_kernel_plans_fall_back():
 def test_bench_line_stays_small_and_carries_the_evidence():
     """the driver's record keeps the fixed keys (roofline whole, scalars only) and about 8 KB of output: the line bench.py
     prints must stay under 6 KB and hold, inside `roofline`, the figures a reader needs first (a full record of a real run,
-    profiles/r04w_bench_full.json, through bench.compact_line)"""
+    profiles/r04x_bench_full.json, through bench.compact_line)"""
     import importlib.util
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    full = json.load(open(os.path.join(root, "profiles", "r04w_bench_full.json")))
+    full = json.load(open(os.path.join(root, "profiles", "r04x_bench_full.json")))
     line = bench.compact_line(full)
     assert len(json.dumps(line)) < 6144
     roof = line["roofline"]
