@@ -261,7 +261,8 @@ def test_bench_line_stays_small_and_carries_the_evidence():
     assert len(json.dumps(line)) < 6144
     roof = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "single_image_us", "single_image_frac", "copy_frac",
-              "oracle_max_abs_diff", "oracle_differing", "rgb8_frac", "min_config_frac", "min_config"):
+              "oracle_max_abs_diff", "oracle_differing", "rgb8_frac", "min_config_frac", "min_config", "second_allocation_frac",
+              "launch_frac_min", "launch_frac_max", "traffic_source"):
         assert k in roof, k
     assert all(not isinstance(v, (dict, list)) for v in roof.values())      # scalars only: nested values are dropped from the record
     assert line["metric"] == full["metric"] and line["cpu_baseline"]["kind"] == "port"
